@@ -1,0 +1,16 @@
+"""MI355X-native train step for frequency-aware inverse-consistent OCTA super-resolution.
+
+Drop-in for the reference's hot path (its ``model.py`` / ``utils.py`` / ``ssim.py`` /
+``pytorch_wavelets`` callables and the loop body of ``train.py``), executed by hand-written
+HIP kernels for gfx950 behind the C ABI of ``include/faoctasr.h``.
+"""
+from . import _lib, ops
+from ._lib import KernelError
+from .model import (Discriminator, FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A, ResidualBlock, ResnetBlock,
+                    ResnetGenerator, TVLoss, UnetGenerator, UnetSkipConnectionBlock, shallowNet)
+from .ssim import SSIM, ssim
+from .train import ParamArena, TrainStep, live_parameters
+from .utils import (LambdaLR, ReplayBuffer, frequency_split, high_pass, low_pass, psnr, set_requires_grad, weights_init_normal)
+from .wavelets import AFB2D, SFB2D, DWTForward, DWTInverse
+
+__all__ = [n for n in dir() if not n.startswith("_")]

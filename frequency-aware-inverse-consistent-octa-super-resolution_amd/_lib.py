@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI declared in include/faoctasr.h.
+
+The product path has no CPU or eager-PyTorch fallback: if libfaoctasr.so is missing or a
+tensor is not a contiguous fp32 device tensor, calls fail loudly."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfaoctasr.so")
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_SIG = {
+    # name: (restype, "argument codes")   p pointer, i int, l long, f float
+    "version": (_I, ""),
+    "last_error": (ctypes.c_char_p, ""),
+    "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p"),
+    "conv2d_dgrad": (_I, "ppp iiiiiiiii p"),
+    "conv2d_wgrad": (_I, "ppp iiiiiiiii i i p"),
+    "conv_transpose2d_fwd": (_I, "pppp iiiiiiiii i i f p"),
+    "conv_transpose2d_dgrad": (_I, "ppp iiiiiiiii i p"),
+    "conv_transpose2d_wgrad": (_I, "ppp iiiiiiiii i i p"),
+    "reflect_pad_bwd": (_I, "pp iiii p"),
+    "channel_sum": (_I, "pp iii i p"),
+    "bn_workspace_floats": (_L, "i"),
+    "batchnorm_train_fwd": (_I, "ppppppppp iii ff i f p p"),
+    "batchnorm_train_bwd": (_I, "pppppppppp iii i f i p p"),
+    "instancenorm_fwd": (_I, "pppppp iii f i f p p"),
+    "instancenorm_bwd": (_I, "ppppppppp iii i f p p"),
+    "act_fwd": (_I, "pp l i f p"),
+    "act_bwd": (_I, "ppp l i f p"),
+    "cat2_act_fwd": (_I, "ppp iiii i f p"),
+    "cat2_act_bwd": (_I, "pppp iiii i f p"),
+    "axpby": (_I, "ppp l ff p"),
+    "haar_dwt2d_fwd": (_I, "ppp l ii p"),
+    "haar_dwt2d_bwd": (_I, "ppp l ii p"),
+    "haar_dfront_fwd": (_I, "pp iii i p"),
+    "haar_dfront_bwd": (_I, "pp iii i p"),
+    "sgemm_batched": (_I, "ppp iii iii lll i p"),
+    "freq_mix_fwd": (_I, "ppppp l p"),
+    "freq_mix_bwd": (_I, "pppppppp l p"),
+    "ssim_fwd": (_I, "ppp iiii p"),
+    "ssim_bwd": (_I, "ppp i f pp iiii p"),
+    "loss_workspace_floats": (_L, ""),
+    "loss_fwd": (_I, "ppp l i f p p"),
+    "loss_bwd": (_I, "pppp l i f i p"),
+    "mean_mix_fwd": (_I, "ppp iii ff p"),
+    "mean_mix_bwd": (_I, "ppp iii ff p"),
+    "adamw_step": (_I, "pppp l fffff i f p"),
+    "fill": (_I, "p l f p"),
+}
+_CODE = {"p": _P, "i": _I, "l": _L, "f": _F}
+
+_lib = None
+
+
+class KernelError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    return ["faoctasr_" + k for k in _SIG]
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KernelError("libfaoctasr.so is not built (%s); run `python __graft_entry__.py` or "
+                          "`python frequency-aware-inverse-consistent-octa-super-resolution_amd/build.py` -- "
+                          "there is no CPU/eager fallback for the product path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, codes) in _SIG.items():
+        fn = getattr(lib, "faoctasr_" + name)
+        fn.restype = res
+        fn.argtypes = [_CODE[c] for c in codes.replace(" ", "")]
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise KernelError("kernel operand must be a contiguous fp32 device tensor, got %s %s contiguous=%s on %s"
+                          % (tuple(t.shape), t.dtype, t.is_contiguous(), t.device))
+    return t.data_ptr()
+
+
+def call(name, *args):
+    lib = _lib or load()
+    rc = getattr(lib, "faoctasr_" + name)(*args)
+    if rc != 0:
+        raise KernelError("faoctasr_%s failed (%d): %s" % (name, rc, lib.faoctasr_last_error().decode()))
+
+
+_ws = {}
+
+
+def workspace(device, nfloats):
+    """Per-(device, stream) scratch reused by the stream-ordered reduction kernels."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _ws.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels (error text, launch checks, activation math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include "faoctasr.h"
+
+namespace faoctasr {
+
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FAOCTASR_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return FAOCTASR_OK;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case FAOCTASR_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FAOCTASR_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case FAOCTASR_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+    switch (act) {
+        case FAOCTASR_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case FAOCTASR_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case FAOCTASR_ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace faoctasr

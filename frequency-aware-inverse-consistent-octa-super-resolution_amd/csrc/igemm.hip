@@ -1,0 +1,471 @@
+// Implicit-GEMM convolution family for gfx950 on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One "tap-list" gather kernel serves nn.Conv2d forward (any stride, zero or reflect padding),
+// conv input-gradient, nn.ConvTranspose2d forward and its input-gradient; one split-K kernel
+// serves every weight gradient.  GEMM view (per phase of the output grid):
+//     Y[m][j] = sum_{k=(c,t)} Wt[m][c][t] * X[n(j)][c][a(j)*SI + oy_t][b(j)*SI + ox_t]
+// m = output channel, j = flattened (n,a,b) over the phase's sub-grid, t = tap.  A strided
+// transposed convolution is split into SO*SO output-parity phases, each a dense stride-1
+// gather over its own subset of taps (the phases partition the KHxKW taps), so no MFMA work
+// is spent on structural zeros.
+//
+// Reference call sites: model.py:102-122 (4x4 s2/s1 convs + bias), 242-258,275-286 (stems),
+// 412-414,438 (3x3 @64ch), 431/469 (ConvTranspose2d), 450-451,472-473 (ReflectionPad2d(3)+7x7),
+// 458 (3x3 s2), 494,499 (3x3 @256ch); backward = aten::convolution_backward under
+// loss.backward() (train.py:238,255,267).
+#include "common.h"
+
+namespace faoctasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmGeom {
+    int N, C, IH, IW;      // gather source tensor
+    int M, OH, OW;         // output tensor
+    int SI, SO;            // input step / output step per sub-grid step
+    int nphase;
+    int reflect;
+    int act;
+    float slope;
+    long wsm, wsc;         // weight strides (elements) for output channel m / gathered channel c
+    int ph_py[4], ph_px[4], ph_gh[4], ph_gw[4], ph_t0[5];
+    int taps[64];          // packed (oy+64) | (ox+64)<<8 | widx<<16
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather ("forward-like") kernel.  Block 256 threads = 4 waves (2 along M x 2 along N),
+// tile MT x 128 pixels, K chunk 16, register-prefetched staging.
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           const IgemmGeom g) {
+    constexpr int NT = 128, KC = 16, LDA = KC + 1;
+    constexpr int MI = MT / 64;          // 32-row MFMA tiles per wave along M
+    constexpr int NA = MT * KC / 256;    // A elements staged per thread
+    __shared__ float A_s[MT * LDA];
+    __shared__ float B_s[KC * NT];
+    __shared__ int taps_s[64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ph = blockIdx.z;
+    const int GH = g.ph_gh[ph], GW = g.ph_gw[ph];
+    const int t0 = g.ph_t0[ph], T = g.ph_t0[ph + 1] - t0;
+    const long npix = (long)g.N * GH * GW;
+    const long j0 = (long)blockIdx.x * NT;
+    if (j0 >= npix) return;
+    const int m0 = blockIdx.y * MT;
+    const int K = g.C * T;
+    const float invT = T > 0 ? 1.0f / (float)T : 0.f;
+    const int IH = g.IH, IW = g.IW;
+    const long chw = (long)IH * IW;
+
+    if (tid < 64) taps_s[tid] = g.taps[tid];
+
+    // this thread's pixel for B staging
+    const int jj = tid & (NT - 1), rg = tid >> 7;
+    const long j = j0 + jj;
+    const bool jv = j < npix;
+    int n = 0, a = 0, b = 0;
+    if (jv) {
+        n = (int)(j / ((long)GH * GW));
+        int r = (int)(j - (long)n * GH * GW);
+        a = r / GW;
+        b = r - a * GW;
+    }
+    const float* xin = x + (long)n * g.C * chw;
+    const int iy0 = a * g.SI, ix0 = b * g.SI;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    float ra[NA], rb[8];
+    __syncthreads();   // taps_s visible
+
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            const int ml = e >> 4, kk = e & 15;
+            const int k = k0 + kk, m = m0 + ml;
+            float v = 0.f;
+            if (m < g.M && k < K) {
+                const int c = (int)(((float)k + 0.5f) * invT);
+                const int t = k - c * T;
+                v = w[(long)m * g.wsm + (long)c * g.wsc + (taps_s[t0 + t] >> 16)];
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + rg + 2 * i;
+            float v = 0.f;
+            if (jv && k < K) {
+                const int c = (int)(((float)k + 0.5f) * invT);
+                const int t = k - c * T;
+                const int tp = taps_s[t0 + t];
+                int iy = iy0 + (tp & 0xff) - 64, ix = ix0 + ((tp >> 8) & 0xff) - 64;
+                if (g.reflect) {
+                    iy = reflect_idx(iy, IH);
+                    ix = reflect_idx(ix, IW);
+                }
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) v = xin[(long)c * chw + (long)iy * IW + ix];
+            }
+            rb[i] = v;
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    load_chunk(0);
+    for (int k0 = 0; k0 < K || k0 == 0; k0 += KC) {
+        __syncthreads();   // previous chunk's MFMA reads are done
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            A_s[(e >> 4) * LDA + (e & 15)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) B_s[(rg + 2 * i) * NT + jj] = rb[i];
+        __syncthreads();
+        if (k0 + KC < K) load_chunk(k0 + KC);   // in flight under the MFMAs below
+#pragma unroll
+        for (int kk0 = 0; kk0 < KC; kk0 += 2) {
+            float af[MI], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = A_s[(wm * (MT / 2) + mi * 32 + l31) * LDA + kk0 + lh];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = B_s[(kk0 + lh) * NT + wn * 64 + ni * 32 + l31];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (K == 0) break;
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int py = g.ph_py[ph], px = g.ph_px[ph];
+    const long ohw = (long)g.OH * g.OW;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const long jo = j0 + wn * 64 + ni * 32 + l31;
+        if (jo >= npix) continue;
+        const int no = (int)(jo / ((long)GH * GW));
+        const int r = (int)(jo - (long)no * GH * GW);
+        const int ao = r / GW, bo = r - ao * GW;
+        const long obase = (long)no * g.M * ohw + (long)(ao * g.SO + py) * g.OW + (bo * g.SO + px);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + wm * (MT / 2) + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                if (m < g.M) {
+                    float v = acc[mi][ni][rr];
+                    if (bias) v += bias[m];
+                    y[obase + (long)m * ohw] = act_apply(v, g.act, g.slope);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernel (split-K over pixels, fp32 atomics into a zeroed dW).
+//   dW[m][c][t] = sum_j dY[n(j)][m][a][b] * X[n(j)][c][a*s+oy_t][b*s+ox_t]
+// tile 64 (m) x 64 (columns (c,t)), pixel chunk 32.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, const IgemmGeom g, int chunks_per_slice) {
+    constexpr int MT = 64, CT = 64, PJ = 32, LD = PJ + 1;
+    __shared__ float A_s[MT * LD];
+    __shared__ float B_s[CT * LD];
+    __shared__ int taps_s[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = g.ph_t0[1];
+    const int K = g.C * T;                      // number of weight columns per output channel
+    const float invT = 1.0f / (float)T;
+    const int m0 = blockIdx.y * MT, col0 = blockIdx.x * CT;
+    const int OH = g.OH, OW = g.OW, IH = g.IH, IW = g.IW;
+    const long npix = (long)g.N * OH * OW;
+    const long nchunks = (npix + PJ - 1) / PJ;
+    const long ch_begin = (long)blockIdx.z * chunks_per_slice;
+    long ch_end = ch_begin + chunks_per_slice;
+    if (ch_end > nchunks) ch_end = nchunks;
+    if (ch_begin >= ch_end) return;
+    if (tid < 64) taps_s[tid] = g.taps[tid];
+    __syncthreads();
+
+    const int pl = tid & 31, rg = tid >> 5;     // pixel within chunk, row group (8 groups)
+    // per-thread fixed columns: cl = rg + 8*i
+    int cc[8], coy[8], cox[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int col = col0 + rg + 8 * i;
+        if (col < K) {
+            const int c = (int)(((float)col + 0.5f) * invT);
+            const int t = col - c * T;
+            const int tp = taps_s[t];
+            cc[i] = c;
+            coy[i] = (tp & 0xff) - 64;
+            cox[i] = ((tp >> 8) & 0xff) - 64;
+        } else {
+            cc[i] = -1; coy[i] = 0; cox[i] = 0;
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const long ihw = (long)IH * IW, ohw = (long)OH * OW;
+    float ra[8], rb[8];
+
+    auto load_chunk = [&](long ch) {
+        const long p = ch * PJ + pl;
+        const bool pv = p < npix;
+        int n = 0, a = 0, b = 0;
+        if (pv) {
+            n = (int)(p / ohw);
+            const int r = (int)(p - (long)n * ohw);
+            a = r / OW;
+            b = r - a * OW;
+        }
+        const float* dyp = dy + (long)n * g.M * ohw + (long)a * OW + b;
+        const float* xp = x + (long)n * g.C * ihw;
+        const int iy0 = a * g.SI, ix0 = b * g.SI;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + rg + 8 * i;
+            ra[i] = (pv && m < g.M) ? dyp[(long)m * ohw] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = 0.f;
+            if (pv && cc[i] >= 0) {
+                int iy = iy0 + coy[i], ix = ix0 + cox[i];
+                if (g.reflect) {
+                    iy = reflect_idx(iy, IH);
+                    ix = reflect_idx(ix, IW);
+                }
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) v = xp[(long)cc[i] * ihw + (long)iy * IW + ix];
+            }
+            rb[i] = v;
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+    load_chunk(ch_begin);
+    for (long ch = ch_begin; ch < ch_end; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            A_s[(rg + 8 * i) * LD + pl] = ra[i];
+            B_s[(rg + 8 * i) * LD + pl] = rb[i];
+        }
+        __syncthreads();
+        if (ch + 1 < ch_end) load_chunk(ch + 1);
+#pragma unroll
+        for (int kk0 = 0; kk0 < PJ; kk0 += 2) {
+            const float af = A_s[(wm * 32 + l31) * LD + kk0 + lh];
+            const float bf = B_s[(wn * 32 + l31) * LD + kk0 + lh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+    }
+    // epilogue: row (m) from the register index, column (c,t) from the lane
+    const int col = col0 + wn * 32 + l31;
+    if (col < K) {
+        const int c = (int)(((float)col + 0.5f) * invT);
+        const int t = col - c * T;
+        float* dst = dw + (long)c * g.wsc + (taps_s[t] >> 16);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int m = m0 + wm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            if (m < g.M) atomicAdd(dst + (long)m * g.wsm, acc[rr]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: geometry builders and launchers
+// ------------------------------------------------------------------------------------------
+static int pack_tap(int oy, int ox, int widx) { return (oy + 64) | ((ox + 64) << 8) | (widx << 16); }
+
+// forward-mode gather: iy = a*stride + (kh - pad)
+static int geom_fwd(IgemmGeom& g, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW, int stride, int pad,
+                    int reflect, long wsm, long wsc) {
+    if (KH * KW > 64 || KH > 16 || KW > 16) return fail(FAOCTASR_EUNSUPPORTED, "kernel %dx%d too large", KH, KW);
+    if (pad > 60) return fail(FAOCTASR_EUNSUPPORTED, "pad %d too large", pad);
+    if (reflect && (pad >= IH || pad >= IW)) return fail(FAOCTASR_EINVAL, "reflect pad %d >= input size", pad);
+    g = IgemmGeom{};
+    g.N = N; g.C = C; g.IH = IH; g.IW = IW; g.M = M; g.OH = OH; g.OW = OW;
+    g.SI = stride; g.SO = 1; g.nphase = 1; g.reflect = reflect; g.wsm = wsm; g.wsc = wsc;
+    g.ph_py[0] = 0; g.ph_px[0] = 0; g.ph_gh[0] = OH; g.ph_gw[0] = OW; g.ph_t0[0] = 0; g.ph_t0[1] = KH * KW;
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < KW; ++kw) g.taps[kh * KW + kw] = pack_tap(kh - pad, kw - pad, kh * KW + kw);
+    return FAOCTASR_OK;
+}
+
+// transposed-mode gather: out (oy,ox) reads src ((oy+pad-kh)/stride, ...) when divisible
+static int geom_transposed(IgemmGeom& g, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW, int stride,
+                           int pad, long wsm, long wsc) {
+    if (KH * KW > 64) return fail(FAOCTASR_EUNSUPPORTED, "kernel %dx%d too large", KH, KW);
+    if (stride < 1 || stride > 2) return fail(FAOCTASR_EUNSUPPORTED, "stride %d unsupported for transposed gather", stride);
+    g = IgemmGeom{};
+    g.N = N; g.C = C; g.IH = IH; g.IW = IW; g.M = M; g.OH = OH; g.OW = OW;
+    g.SI = 1; g.SO = stride; g.nphase = stride * stride; g.reflect = 0; g.wsm = wsm; g.wsc = wsc;
+    int nt = 0;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            const int ph = py * stride + px;
+            g.ph_py[ph] = py; g.ph_px[ph] = px;
+            g.ph_gh[ph] = OH > py ? (OH - py + stride - 1) / stride : 0;
+            g.ph_gw[ph] = OW > px ? (OW - px + stride - 1) / stride : 0;
+            g.ph_t0[ph] = nt;
+            for (int kh = 0; kh < KH; ++kh) {
+                int ny = py + pad - kh;
+                if (((ny % stride) + stride) % stride) continue;
+                for (int kw = 0; kw < KW; ++kw) {
+                    int nx = px + pad - kw;
+                    if (((nx % stride) + stride) % stride) continue;
+                    // exact division (ny, nx are multiples of stride, possibly negative)
+                    g.taps[nt++] = pack_tap(ny / stride, nx / stride, kh * KW + kw);
+                }
+            }
+            g.ph_t0[ph + 1] = nt;
+        }
+    return FAOCTASR_OK;
+}
+
+static int launch_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope,
+                         hipStream_t s) {
+    g.act = act; g.slope = slope;
+    long maxpix = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        long np = (long)g.N * g.ph_gh[p] * g.ph_gw[p];
+        if (np > maxpix) maxpix = np;
+    }
+    if (maxpix == 0 || g.M == 0) return FAOCTASR_OK;
+    const long gx = (maxpix + 127) / 128;
+    if (gx > 0x7fffffffL) return fail(FAOCTASR_EUNSUPPORTED, "grid too large");
+    const long blocks128 = gx * ((g.M + 127) / 128) * g.nphase;
+    if (g.M >= 128 && blocks128 >= 512) {
+        dim3 grid((unsigned)gx, (g.M + 127) / 128, g.nphase);
+        hipLaunchKernelGGL(igemm_gather_kernel<128>, grid, dim3(256), 0, s, x, w, bias, y, g);
+    } else {
+        dim3 grid((unsigned)gx, (g.M + 63) / 64, g.nphase);
+        hipLaunchKernelGGL(igemm_gather_kernel<64>, grid, dim3(256), 0, s, x, w, bias, y, g);
+    }
+    return check_launch("igemm_gather");
+}
+
+static int launch_wgrad(const float* x, const float* dy, float* dw, IgemmGeom& g, long dw_elems, int accumulate, hipStream_t s) {
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * dw_elems, s);
+        if (e != hipSuccess) return fail(FAOCTASR_EHIP, "memset dw: %s", hipGetErrorString(e));
+    }
+    const int K = g.C * g.ph_t0[1];
+    const long npix = (long)g.N * g.OH * g.OW;
+    if (npix == 0 || K == 0 || g.M == 0) return FAOCTASR_OK;
+    const long nchunks = (npix + 31) / 32;
+    const int gx = (K + 63) / 64, gy = (g.M + 63) / 64;
+    long slices = 2048 / ((long)gx * gy);
+    if (slices < 1) slices = 1;
+    if (slices > nchunks) slices = nchunks;
+    if (slices > 65535) slices = 65535;
+    const int cps = (int)((nchunks + slices - 1) / slices);
+    slices = (nchunks + cps - 1) / cps;
+    dim3 grid(gx, gy, (unsigned)slices);
+    hipLaunchKernelGGL(igemm_wgrad_kernel, grid, dim3(256), 0, s, x, dy, dw, g, cps);
+    return check_launch("igemm_wgrad");
+}
+
+static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || !b || !c; }
+
+}  // namespace faoctasr
+
+using namespace faoctasr;
+
+extern "C" {
+
+int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,
+                        int KH, int KW, int stride, int pad, int reflect, int act, float slope, faoctasr_stream_t stream) {
+    if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv2d_fwd: null pointer");
+    if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: kernel (%d x %d) larger than padded input (%d x %d)", KH, KW, IH + 2 * pad, IW + 2 * pad);
+    IgemmGeom g;
+    int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
+    if (rc) return rc;
+    return launch_gather(x, w, bias, y, g, act, slope, (hipStream_t)stream);
+}
+
+int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW,
+                          int stride, int pad, faoctasr_stream_t stream) {
+    if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
+    IgemmGeom g;
+    // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
+    int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
+    if (rc) return rc;
+    return launch_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, (hipStream_t)stream);
+}
+
+int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
+                          int stride, int pad, int reflect, int accumulate, faoctasr_stream_t stream) {
+    if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
+    const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");
+    IgemmGeom g;
+    int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
+    if (rc) return rc;
+    return launch_wgrad(x, dy, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
+}
+
+int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW,
+                                  int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope,
+                                  faoctasr_stream_t stream) {
+    if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: null pointer");
+    const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: bad shape");
+    IgemmGeom g;
+    // w[c][m][t]: m stride = KK, c stride = M*KK
+    int rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, (long)KH * KW, (long)M * KH * KW);
+    if (rc) return rc;
+    return launch_gather(x, w, bias, y, g, act, slope, (hipStream_t)stream);
+}
+
+int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH,
+                                    int KW, int stride, int pad, int out_pad, faoctasr_stream_t stream) {
+    if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_dgrad: null pointer");
+    const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
+    IgemmGeom g;
+    // dx[n][c][iy][ix] = sum_{m,t} dy[n][m][iy*s-p+kh][..] * w[c][m][t]: forward-mode gather over dy
+    int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
+    if (rc) return rc;
+    return launch_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, (hipStream_t)stream);
+}
+
+int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,
+                                    int KW, int stride, int pad, int out_pad, int accumulate, faoctasr_stream_t stream) {
+    if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: null pointer");
+    const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
+    IgemmGeom g;
+    // dw[c][m][t] = sum x[n][c][iy][ix] * dy[n][m][iy*s-p+kh][..]: conv-wgrad with source dy (M channels) and "dY" = x
+    int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
+    if (rc) return rc;
+    return launch_wgrad(dy, x, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,809 @@
+// HBM-bound kernels of the train step: BatchNorm2d(train)/InstanceNorm2d with fused
+// activation + residual, activations, cat, Haar DWT/IDWT, frequency-split mixing, losses,
+// discriminator head, AdamW.  All fp32, NCHW, float4-vectorised where the shape allows.
+#include "common.h"
+
+namespace faoctasr {
+
+thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline int grid_for(long n, int per_block, int cap = 4096) {
+    long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// normalisation.  Rows r in [0,R): BatchNorm R = C (each row gathers N images x HW);
+// InstanceNorm R = N*C with N_img = 1.  Element e of row r lives at ((e/HW)*R + r)*HW + e%HW.
+// Statistics are accumulated around a per-row shift (the row's first element) to avoid the
+// E[x^2]-E[x]^2 cancellation.  Partials: ws[(r*S + s)*2 + {0,1}].
+// ------------------------------------------------------------------------------------------
+constexpr int BN_MAX_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int NI, int R,
+                                                         int HW, int S, long per) {
+    __shared__ float red[4];
+    const int r = blockIdx.y, s = blockIdx.x;
+    const long L = (long)NI * HW;
+    long e0 = (long)s * per, e1 = e0 + per;
+    if (e1 > L) e1 = L;
+    const float shift = x[(long)r * HW];
+    float a = 0.f, q = 0.f;
+    if ((HW & 3) == 0) {
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
+            const long n = e / HW;
+            const long i = e - n * HW;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((long)n * R + r) * HW + i);
+            float d;
+            d = v.x - shift; a += d; q += d * d;
+            d = v.y - shift; a += d; q += d * d;
+            d = v.z - shift; a += d; q += d * d;
+            d = v.w - shift; a += d; q += d * d;
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+            const long n = e / HW;
+            const long i = e - n * HW;
+            const float d = x[((long)n * R + r) * HW + i] - shift;
+            a += d; q += d * d;
+        }
+    }
+    a = block_sum_256(a, red);
+    q = block_sum_256(q, red);
+    if (threadIdx.x == 0) {
+        ws[((long)r * S + s) * 2 + 0] = a;
+        ws[((long)r * S + s) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ res,
+                                                         float* __restrict__ y, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_invstd, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, const float* __restrict__ ws, int NI, int R,
+                                                         int Cg, int HW, int S, float eps, float momentum, int act, float slope,
+                                                         long per) {
+    const int r = blockIdx.y;
+    const long L = (long)NI * HW;
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < S; ++s) {   // fixed order: deterministic
+        a += ws[((long)r * S + s) * 2 + 0];
+        q += ws[((long)r * S + s) * 2 + 1];
+    }
+    const float shift = x[(long)r * HW];
+    const float invL = 1.0f / (float)L;
+    const float dm = a * invL;
+    const float mean = shift + dm;
+    float var = q * invL - dm * dm;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        save_mean[r] = mean;
+        save_invstd[r] = invstd;
+        if (rmean) {
+            const float unb = L > 1 ? var * ((float)L / (float)(L - 1)) : var;
+            rmean[r] = (1.f - momentum) * rmean[r] + momentum * mean;
+            rvar[r] = (1.f - momentum) * rvar[r] + momentum * unb;
+        }
+    }
+    const int cg = r % Cg;
+    const float gsc = (gamma ? gamma[cg] : 1.f) * invstd;
+    const float bsh = (beta ? beta[cg] : 0.f) - mean * gsc;
+    long e0 = (long)blockIdx.x * per, e1 = e0 + per;
+    if (e1 > L) e1 = L;
+    if ((HW & 3) == 0) {
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            float4 v = *reinterpret_cast<const float4*>(x + off);
+            v.x = v.x * gsc + bsh; v.y = v.y * gsc + bsh; v.z = v.z * gsc + bsh; v.w = v.w * gsc + bsh;
+            if (res) {
+                const float4 rr = *reinterpret_cast<const float4*>(res + off);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
+            v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
+            *reinterpret_cast<float4*>(y + off) = v;
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            float v = x[off] * gsc + bsh;
+            if (res) v += res[off];
+            y[off] = act_apply(v, act, slope);
+        }
+    }
+}
+
+// backward reduce: s1 = sum dy', s2 = sum dy' * xhat, dy' = dy * act'(y)
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ y, const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_invstd, float* __restrict__ ws,
+                                                              int NI, int R, int HW, int S, int act, float slope, long per) {
+    __shared__ float red[4];
+    const int r = blockIdx.y, s = blockIdx.x;
+    const long L = (long)NI * HW;
+    long e0 = (long)s * per, e1 = e0 + per;
+    if (e1 > L) e1 = L;
+    const float mean = save_mean[r], invstd = save_invstd[r];
+    float s1 = 0.f, s2 = 0.f;
+    if ((HW & 3) == 0) {
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            float4 g = *reinterpret_cast<const float4*>(dy + off);
+            if (act != FAOCTASR_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + off);
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            s1 += g.x + g.y + g.z + g.w;
+            s2 += g.x * ((xv.x - mean) * invstd) + g.y * ((xv.y - mean) * invstd) + g.z * ((xv.z - mean) * invstd) +
+                  g.w * ((xv.w - mean) * invstd);
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            float g = dy[off];
+            if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[off], act, slope);
+            s1 += g;
+            s2 += g * ((x[off] - mean) * invstd);
+        }
+    }
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        ws[((long)r * S + s) * 2 + 0] = s1;
+        ws[((long)r * S + s) * 2 + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ y, const float* __restrict__ gamma,
+                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                          float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ dres, const float* __restrict__ ws, int NI, int R, int Cg,
+                                                          int HW, int S, int act, float slope, long per, int accumulate_affine) {
+    const int r = blockIdx.y;
+    const long L = (long)NI * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < S; ++s) {
+        s1 += ws[((long)r * S + s) * 2 + 0];
+        s2 += ws[((long)r * S + s) * 2 + 1];
+    }
+    const int cg = r % Cg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (accumulate_affine) {
+            if (dgamma) atomicAdd(dgamma + cg, s2);
+            if (dbeta) atomicAdd(dbeta + cg, s1);
+        } else {
+            if (dgamma) dgamma[cg] = s2;
+            if (dbeta) dbeta[cg] = s1;
+        }
+    }
+    const float mean = save_mean[r], invstd = save_invstd[r];
+    const float gi = (gamma ? gamma[cg] : 1.f) * invstd;
+    const float m1 = s1 / (float)L, m2 = s2 / (float)L;
+    long e0 = (long)blockIdx.x * per, e1 = e0 + per;
+    if (e1 > L) e1 = L;
+    if ((HW & 3) == 0) {
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            float4 g = *reinterpret_cast<const float4*>(dy + off);
+            if (act != FAOCTASR_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + off);
+                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
+                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
+            }
+            if (dres) *reinterpret_cast<float4*>(dres + off) = g;
+            float4 o;
+            o.x = gi * (g.x - m1 - (xv.x - mean) * invstd * m2);
+            o.y = gi * (g.y - m1 - (xv.y - mean) * invstd * m2);
+            o.z = gi * (g.z - m1 - (xv.z - mean) * invstd * m2);
+            o.w = gi * (g.w - m1 - (xv.w - mean) * invstd * m2);
+            *reinterpret_cast<float4*>(dx + off) = o;
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+            const long n = e / HW;
+            const long off = ((long)n * R + r) * HW + (e - n * HW);
+            float g = dy[off];
+            if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[off], act, slope);
+            if (dres) dres[off] = g;
+            dx[off] = gi * (g - m1 - (x[off] - mean) * invstd * m2);
+        }
+    }
+}
+
+static void norm_split(long L, int R, int& S, long& per) {
+    // enough blocks to fill 256 CUs a few times over, each block >= 4096 elements
+    long want = (1024 + R - 1) / R;
+    long maxs = (L + 4095) / 4096;
+    long s = want < maxs ? want : maxs;
+    if (s < 1) s = 1;
+    if (s > BN_MAX_SPLIT) s = BN_MAX_SPLIT;
+    per = (L + s - 1) / s;
+    per = (per + 3) & ~3L;
+    S = (int)((L + per - 1) / per);
+}
+
+static int norm_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, float* save_mean,
+                    float* save_invstd, float* rmean, float* rvar, int NI, int R, int Cg, int HW, float eps, float momentum,
+                    int act, float slope, float* ws, hipStream_t st) {
+    if (!x || !y || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_fwd: null pointer");
+    if (NI <= 0 || R <= 0 || HW <= 0) return fail(FAOCTASR_EINVAL, "norm_fwd: bad shape");
+    const long L = (long)NI * HW;
+    int S; long per;
+    norm_split(L, R, S, per);
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(S, R), dim3(256), 0, st, x, ws, NI, R, HW, S, per);
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(S, R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar,
+                       ws, NI, R, Cg, HW, S, eps, momentum, act, slope, per);
+    return check_launch("norm_fwd");
+}
+
+static int norm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dres, int NI, int R, int Cg, int HW,
+                    int act, float slope, int accumulate_affine, float* ws, hipStream_t st) {
+    if (!x || !dy || !dx || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_bwd: null pointer");
+    if (act != FAOCTASR_ACT_NONE && !y) return fail(FAOCTASR_EINVAL, "norm_bwd: activation mask needs the forward output");
+    const long L = (long)NI * HW;
+    int S; long per;
+    norm_split(L, R, S, per);
+    const int accumulate = (Cg != R) || accumulate_affine;
+    if (accumulate && !accumulate_affine) {
+        if (dgamma) (void)hipMemsetAsync(dgamma, 0, sizeof(float) * Cg, st);
+        if (dbeta) (void)hipMemsetAsync(dbeta, 0, sizeof(float) * Cg, st);
+    }
+    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, ws, NI, R, HW, S, act,
+                       slope, per);
+    hipLaunchKernelGGL(norm_bwd_dx_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta,
+                       dres, ws, NI, R, Cg, HW, S, act, slope, per, accumulate);
+    return check_launch("norm_bwd");
+}
+
+// ------------------------------------------------------------------------------------------
+// pointwise
+// ------------------------------------------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
+        v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = act_apply(x[i], act, slope);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n, int act,
+                               float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        g.x *= act_grad_from_out(v.x, act, slope); g.y *= act_grad_from_out(v.y, act, slope);
+        g.z *= act_grad_from_out(v.z, act, slope); g.w *= act_grad_from_out(v.w, act, slope);
+        reinterpret_cast<float4*>(dx)[i] = g;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dx[i] = dy[i] * act_grad_from_out(y[i], act, slope);
+}
+
+// y[n, 0:Ca] = act(a[n]), y[n, Ca:Ca+Cb] = act(b[n]); rows of length HW (per-image blocks contiguous)
+__global__ void cat2_act_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int N, long la,
+                                    long lb, int act, float slope) {
+    const long tot = (long)N * (la + lb);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long n = i / (la + lb);
+        const long r = i - n * (la + lb);
+        const float v = r < la ? a[n * la + r] : b[n * lb + (r - la)];
+        y[i] = act_apply(v, act, slope);
+    }
+}
+
+__global__ void cat2_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ da,
+                                    float* __restrict__ db, int N, long la, long lb, int act, float slope) {
+    const long tot = (long)N * (la + lb);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long n = i / (la + lb);
+        const long r = i - n * (la + lb);
+        float g = dy[i];
+        if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[i], act, slope);
+        if (r < la) {
+            if (da) da[n * la + r] = g;
+        } else if (db) {
+            db[n * lb + (r - la)] = g;
+        }
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n, float alpha,
+                             float beta) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = alpha * a[i] + beta * b[i];
+}
+
+__global__ void fill_kernel(float* __restrict__ p, long n, float v) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// per-channel sum over (N, HW): grid (C), block 256
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int C, int HW,
+                                                          int accumulate) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const long L = (long)N * HW;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < L; e += 256) {
+        const long n = e / HW;
+        s += dy[((long)n * C + c) * HW + (e - n * HW)];
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+// fold of the gradient of ReflectionPad2d(p): each padded position maps back to one source pixel
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dxp, float* __restrict__ dx, long NC, int H, int W, int p) {
+    const long tot = NC * H * W;
+    const int HP = H + 2 * p, WP = W + 2 * p;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long nc = i / ((long)H * W);
+        const int r = (int)(i - nc * H * W);
+        const int yy = r / W, xx = r - yy * W;
+        // source pixel (yy,xx) appears at padded rows {yy+p} plus mirrored rows when 1<=yy<=p or H-1-p<=yy<=H-2
+        int ry[3], rx[3], ny = 0, nx = 0;
+        ry[ny++] = yy + p;
+        if (yy >= 1 && yy <= p) ry[ny++] = p - yy;
+        if (yy <= H - 2 && yy >= H - 1 - p) ry[ny++] = 2 * (H - 1) - yy + p;
+        rx[nx++] = xx + p;
+        if (xx >= 1 && xx <= p) rx[nx++] = p - xx;
+        if (xx <= W - 2 && xx >= W - 1 - p) rx[nx++] = 2 * (W - 1) - xx + p;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) s += dxp[(nc * HP + ry[a]) * WP + rx[b]];
+        dx[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Haar DWT / IDWT.  One thread = one 2x2 input block.
+// ------------------------------------------------------------------------------------------
+__global__ void haar_fwd_kernel(const float* __restrict__ x, float* __restrict__ ll, float* __restrict__ hi, long NC, int H, int W) {
+    const int h = H >> 1, w = W >> 1;
+    const long tot = NC * h * w;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long nc = i / ((long)h * w);
+        const int r = (int)(i - nc * h * w);
+        const int yy = r / w, xx = r - yy * w;
+        const float* p = x + (nc * H + 2 * yy) * W + 2 * xx;
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        const float2 u = *reinterpret_cast<const float2*>(p + W);
+        const float a = t.x, b = t.y, c = u.x, d = u.y;
+        if (ll) ll[i] = (a + b + c + d) * 0.5f;
+        if (hi) {
+            float* q = hi + (nc * 3) * h * w + r;
+            q[0] = (a + b - c - d) * 0.5f;
+            q[(long)h * w] = (a - b + c - d) * 0.5f;
+            q[2L * h * w] = (a - b - c + d) * 0.5f;
+        }
+    }
+}
+
+// synthesis: x 2x2 block from (ll, lh, hl, hh); NULL inputs are zeros.  Serves AFB2D.backward and SFB2D.forward.
+__global__ void haar_inv_kernel(const float* __restrict__ ll, const float* __restrict__ hi, float* __restrict__ x, long NC, int H, int W) {
+    const int h = H >> 1, w = W >> 1;
+    const long tot = NC * h * w;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long nc = i / ((long)h * w);
+        const int r = (int)(i - nc * h * w);
+        const int yy = r / w, xx = r - yy * w;
+        const float l = ll ? ll[i] : 0.f;
+        float lh = 0.f, hl = 0.f, hh = 0.f;
+        if (hi) {
+            const float* q = hi + (nc * 3) * h * w + r;
+            lh = q[0]; hl = q[(long)h * w]; hh = q[2L * h * w];
+        }
+        float* p = x + (nc * H + 2 * yy) * W + 2 * xx;
+        *reinterpret_cast<float2*>(p) = make_float2((l + lh + hl + hh) * 0.5f, (l + lh - hl - hh) * 0.5f);
+        *reinterpret_cast<float2*>(p + W) = make_float2((l - lh + hl - hh) * 0.5f, (l - lh - hl + hh) * 0.5f);
+    }
+}
+
+// discriminator front ends on single-channel images: mode 0 -> y[N,1,h,w] = LL; mode 1 -> y[N,3,h,w] = (LH,HL,HH)*0.5+0.5
+__global__ void haar_dfront_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int mode) {
+    const int h = H >> 1, w = W >> 1;
+    const long tot = (long)N * h * w;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long n = i / ((long)h * w);
+        const int r = (int)(i - n * h * w);
+        const int yy = r / w, xx = r - yy * w;
+        const float* p = x + (n * H + 2 * yy) * W + 2 * xx;
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        const float2 u = *reinterpret_cast<const float2*>(p + W);
+        const float a = t.x, b = t.y, c = u.x, d = u.y;
+        if (mode == 0) {
+            y[i] = (a + b + c + d) * 0.5f;
+        } else {
+            float* q = y + n * 3 * h * w + r;
+            q[0] = (a + b - c - d) * 0.25f + 0.5f;
+            q[(long)h * w] = (a - b + c - d) * 0.25f + 0.5f;
+            q[2L * h * w] = (a - b - c + d) * 0.25f + 0.5f;
+        }
+    }
+}
+
+__global__ void haar_dfront_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int mode) {
+    const int h = H >> 1, w = W >> 1;
+    const long tot = (long)N * h * w;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
+        const long n = i / ((long)h * w);
+        const int r = (int)(i - n * h * w);
+        const int yy = r / w, xx = r - yy * w;
+        float l = 0.f, lh = 0.f, hl = 0.f, hh = 0.f;
+        if (mode == 0) {
+            l = dy[i];
+        } else {
+            const float* q = dy + n * 3 * h * w + r;
+            lh = q[0] * 0.5f; hl = q[(long)h * w] * 0.5f; hh = q[2L * h * w] * 0.5f;
+        }
+        float* p = dx + (n * H + 2 * yy) * W + 2 * xx;
+        *reinterpret_cast<float2*>(p) = make_float2((l + lh + hl + hh) * 0.5f, (l + lh - hl - hh) * 0.5f);
+        *reinterpret_cast<float2*>(p + W) = make_float2((l - lh + hl - hh) * 0.5f, (l - lh - hl + hh) * 0.5f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// frequency split mixing
+// ------------------------------------------------------------------------------------------
+__global__ void freq_mix_fwd_kernel(const float* __restrict__ x, const float* __restrict__ lo_hp, const float* __restrict__ lo_lp,
+                                    float* __restrict__ hf, float* __restrict__ lf, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xv = x[i];
+        hf[i] = (fabsf(xv - lo_hp[i]) + xv) * 0.5f;
+        lf[i] = -fabsf(lo_lp[i]);
+    }
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void freq_mix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lo_hp, const float* __restrict__ lo_lp,
+                                    const float* __restrict__ g_hf, const float* __restrict__ g_lf, float* __restrict__ s_hp,
+                                    float* __restrict__ s_lp, float* __restrict__ dx_direct, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gh = g_hf ? g_hf[i] : 0.f, gl = g_lf ? g_lf[i] : 0.f;
+        const float sh = 0.5f * gh * sgn(x[i] - lo_hp[i]);
+        s_hp[i] = sh;
+        s_lp[i] = -gl * sgn(lo_lp[i]);
+        dx_direct[i] = 0.5f * gh + sh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// losses, discriminator head, AdamW
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float loss_term(float a, float b, int kind) {
+    if (kind == 0) { const float d = a - b; return d * d; }
+    if (kind == 1) return fabsf(a - b);
+    // BCEWithLogits(input=a, target=b) = max(a,0) - a*b + log(1+exp(-|a|))
+    return fmaxf(a, 0.f) - a * b + log1pf(expf(-fabsf(a)));
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ part, long n, int kind) {
+    __shared__ float red[4];
+    const long stride = (long)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += loss_term(a[i], b[i], kind);
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ part, int np, float* __restrict__ out, float scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+__global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                float* __restrict__ d, long n, int kind, float scale, int wrt) {
+    const float gs = g[0] * scale;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float av = a[i], bv = b[i];
+        float v;
+        if (kind == 0) v = 2.f * (av - bv) * (wrt == 0 ? 1.f : -1.f);
+        else if (kind == 1) v = sgn(av - bv) * (wrt == 0 ? 1.f : -1.f);
+        else v = wrt == 0 ? (1.f / (1.f + expf(-av)) - bv) : -av;
+        d[i] = gs * v;
+    }
+}
+
+__global__ __launch_bounds__(256) void mean_mix_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, int La, int Lb, float wa, float wb) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x; i < La; i += 256) sa += a[(long)n * La + i];
+    for (int i = threadIdx.x; i < Lb; i += 256) sb += b[(long)n * Lb + i];
+    sa = block_sum_256(sa, red);
+    sb = block_sum_256(sb, red);
+    if (threadIdx.x == 0) out[n] = wa * (sa / (float)La) + wb * (sb / (float)Lb);
+}
+
+__global__ void mean_mix_bwd_kernel(const float* __restrict__ g, float* __restrict__ da, float* __restrict__ db, int La, int Lb,
+                                    float wa, float wb) {
+    const int n = blockIdx.x;
+    const float gv = g[n];
+    if (da) for (int i = threadIdx.x; i < La; i += blockDim.x) da[(long)n * La + i] = gv * wa / (float)La;
+    if (db) for (int i = threadIdx.x; i < Lb; i += blockDim.x) db[(long)n * Lb + i] = gv * wb / (float)Lb;
+}
+
+// torch.optim.AdamW single-tensor arithmetic order: decay, moments, bias corrections, update
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2, float gscale) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] * gscale;
+            float pk = pp[k] * (1.f - lr * wd);
+            mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+            vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+            const float denom = sqrtf(vp[k]) * inv_sqrt_bc2 + eps;
+            pp[k] = pk - step_size * (mp[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gg = g[i] * gscale;
+        float pk = p[i] * (1.f - lr * wd);
+        m[i] = b1 * m[i] + (1.f - b1) * gg;
+        v[i] = b2 * v[i] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
+        p[i] = pk - step_size * (m[i] / denom);
+    }
+}
+
+}  // namespace faoctasr
+
+using namespace faoctasr;
+
+extern "C" {
+
+int faoctasr_version(void) { return 100; }
+const char* faoctasr_last_error(void) { return err_buf(); }
+
+long faoctasr_bn_workspace_floats(int C) { return (long)C * BN_MAX_SPLIT * 2; }
+
+int faoctasr_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                 float* save_mean, float* save_invstd, float* running_mean, float* running_var, int N, int C,
+                                 int HW, float eps, float momentum, int act, float slope, float* workspace, faoctasr_stream_t stream) {
+    return norm_fwd(x, gamma, beta, residual, y, save_mean, save_invstd, running_mean, running_var, N, C, C, HW, eps, momentum, act,
+                    slope, workspace, (hipStream_t)stream);
+}
+
+int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dres, int N, int C, int HW,
+                                 int act, float slope, int accumulate_affine, float* workspace, faoctasr_stream_t stream) {
+    return norm_bwd(x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, dres, N, C, C, HW, act, slope, accumulate_affine,
+                    workspace, (hipStream_t)stream);
+}
+
+// InstanceNorm2d = the same kernels over R = N*C rows of one image each (workspace: faoctasr_bn_workspace_floats(N*C))
+int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                              int N, int C, int HW, float eps, int act, float slope, float* workspace, faoctasr_stream_t stream) {
+    return norm_fwd(x, gamma, beta, nullptr, y, save_mean, save_invstd, nullptr, nullptr, 1, N * C, C, HW, eps, 0.f, act, slope,
+                    workspace, (hipStream_t)stream);
+}
+
+int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                              const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, int HW, int act,
+                              float slope, float* workspace, faoctasr_stream_t stream) {
+    return norm_bwd(x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, 1, N * C, C, HW, act, slope, 0, workspace,
+                    (hipStream_t)stream);
+}
+
+int faoctasr_act_fwd(const float* x, float* y, long n, int act, float slope, faoctasr_stream_t stream) {
+    if (!x || !y) return fail(FAOCTASR_EINVAL, "act_fwd: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, y, n, act, slope);
+    return check_launch("act_fwd");
+}
+
+int faoctasr_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, faoctasr_stream_t stream) {
+    if (!dy || !y || !dx) return fail(FAOCTASR_EINVAL, "act_bwd: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n, act, slope);
+    return check_launch("act_bwd");
+}
+
+int faoctasr_cat2_act_fwd(const float* a, const float* b, float* y, int N, int Ca, int Cb, int HW, int act, float slope,
+                          faoctasr_stream_t stream) {
+    if (!a || !b || !y) return fail(FAOCTASR_EINVAL, "cat2_act_fwd: null pointer");
+    const long tot = (long)N * (Ca + Cb) * HW;
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(cat2_act_fwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, N, (long)Ca * HW,
+                       (long)Cb * HW, act, slope);
+    return check_launch("cat2_act_fwd");
+}
+
+int faoctasr_cat2_act_bwd(const float* dy, const float* y, float* da, float* db, int N, int Ca, int Cb, int HW, int act, float slope,
+                          faoctasr_stream_t stream) {
+    if (!dy) return fail(FAOCTASR_EINVAL, "cat2_act_bwd: null pointer");
+    if (act != FAOCTASR_ACT_NONE && !y) return fail(FAOCTASR_EINVAL, "cat2_act_bwd: mask needs y");
+    const long tot = (long)N * (Ca + Cb) * HW;
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(cat2_act_bwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, da, db, N,
+                       (long)Ca * HW, (long)Cb * HW, act, slope);
+    return check_launch("cat2_act_bwd");
+}
+
+int faoctasr_axpby(const float* a, const float* b, float* y, long n, float alpha, float beta, faoctasr_stream_t stream) {
+    if (!a || !b || !y) return fail(FAOCTASR_EINVAL, "axpby: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n, alpha, beta);
+    return check_launch("axpby");
+}
+
+int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream) {
+    if (!p) return fail(FAOCTASR_EINVAL, "fill: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+    return check_launch("fill");
+}
+
+int faoctasr_channel_sum(const float* dy, float* db, int N, int C, int HW, int accumulate, faoctasr_stream_t stream) {
+    if (!dy || !db) return fail(FAOCTASR_EINVAL, "channel_sum: null pointer");
+    if (C <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, N, C, HW, accumulate);
+    return check_launch("channel_sum");
+}
+
+int faoctasr_reflect_pad_bwd(const float* dxp, float* dx, int NC, int H, int W, int p, faoctasr_stream_t stream) {
+    if (!dxp || !dx) return fail(FAOCTASR_EINVAL, "reflect_pad_bwd: null pointer");
+    if (p >= H || p >= W) return fail(FAOCTASR_EINVAL, "reflect_pad_bwd: pad >= size");
+    const long tot = (long)NC * H * W;
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, dxp, dx, (long)NC, H, W, p);
+    return check_launch("reflect_pad_bwd");
+}
+
+int faoctasr_haar_dwt2d_fwd(const float* x, float* ll, float* hi, long NC, int H, int W, faoctasr_stream_t stream) {
+    if (!x) return fail(FAOCTASR_EINVAL, "haar_dwt2d_fwd: null pointer");
+    if ((H & 1) || (W & 1)) return fail(FAOCTASR_EUNSUPPORTED, "haar_dwt2d: odd size %dx%d (reference path uses even sizes only)", H, W);
+    const long tot = NC * (H / 2) * (W / 2);
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(haar_fwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, ll, hi, NC, H, W);
+    return check_launch("haar_fwd");
+}
+
+int faoctasr_haar_dwt2d_bwd(const float* dll, const float* dhi, float* dx, long NC, int H, int W, faoctasr_stream_t stream) {
+    if (!dx) return fail(FAOCTASR_EINVAL, "haar_dwt2d_bwd: null pointer");
+    if ((H & 1) || (W & 1)) return fail(FAOCTASR_EUNSUPPORTED, "haar_dwt2d: odd size %dx%d", H, W);
+    const long tot = NC * (H / 2) * (W / 2);
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(haar_inv_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, dll, dhi, dx, NC, H, W);
+    return check_launch("haar_inv");
+}
+
+int faoctasr_haar_dfront_fwd(const float* x, float* y, int N, int H, int W, int mode, faoctasr_stream_t stream) {
+    if (!x || !y) return fail(FAOCTASR_EINVAL, "haar_dfront_fwd: null pointer");
+    if ((H & 1) || (W & 1)) return fail(FAOCTASR_EUNSUPPORTED, "haar_dfront: odd size");
+    const long tot = (long)N * (H / 2) * (W / 2);
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(haar_dfront_fwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, mode);
+    return check_launch("haar_dfront_fwd");
+}
+
+int faoctasr_haar_dfront_bwd(const float* dy, float* dx, int N, int H, int W, int mode, faoctasr_stream_t stream) {
+    if (!dy || !dx) return fail(FAOCTASR_EINVAL, "haar_dfront_bwd: null pointer");
+    const long tot = (long)N * (H / 2) * (W / 2);
+    if (tot <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(haar_dfront_bwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, mode);
+    return check_launch("haar_dfront_bwd");
+}
+
+int faoctasr_freq_mix_fwd(const float* x, const float* low_hp, const float* low_lp, float* hf, float* lf, long n,
+                          faoctasr_stream_t stream) {
+    if (!x || !low_hp || !low_lp || !hf || !lf) return fail(FAOCTASR_EINVAL, "freq_mix_fwd: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(freq_mix_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, low_hp, low_lp, hf, lf, n);
+    return check_launch("freq_mix_fwd");
+}
+
+int faoctasr_freq_mix_bwd(const float* x, const float* low_hp, const float* low_lp, const float* g_hf, const float* g_lf, float* s_hp,
+                          float* s_lp, float* dx_direct, long n, faoctasr_stream_t stream) {
+    if (!x || !low_hp || !low_lp || !s_hp || !s_lp || !dx_direct) return fail(FAOCTASR_EINVAL, "freq_mix_bwd: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(freq_mix_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, low_hp, low_lp, g_hf, g_lf,
+                       s_hp, s_lp, dx_direct, n);
+    return check_launch("freq_mix_bwd");
+}
+
+long faoctasr_loss_workspace_floats(void) { return 1024; }
+
+int faoctasr_loss_fwd(const float* a, const float* b, float* out, long n, int kind, float scale, float* workspace,
+                      faoctasr_stream_t stream) {
+    if (!a || !b || !out || !workspace) return fail(FAOCTASR_EINVAL, "loss_fwd: null pointer");
+    if (kind < 0 || kind > 2) return fail(FAOCTASR_EINVAL, "loss_fwd: unknown kind %d", kind);
+    const int nb = n > 0 ? grid_for(n, 2048, 1024) : 0;
+    if (nb) hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, workspace, n, kind);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nb, out, scale);
+    return check_launch("loss_fwd");
+}
+
+int faoctasr_loss_bwd(const float* a, const float* b, const float* g, float* d, long n, int kind, float scale, int wrt,
+                      faoctasr_stream_t stream) {
+    if (!a || !b || !g || !d) return fail(FAOCTASR_EINVAL, "loss_bwd: null pointer");
+    if (kind < 0 || kind > 2) return fail(FAOCTASR_EINVAL, "loss_bwd: unknown kind %d", kind);
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, d, n, kind, scale, wrt);
+    return check_launch("loss_bwd");
+}
+
+int faoctasr_mean_mix_fwd(const float* a, const float* b, float* out, int N, int La, int Lb, float wa, float wb,
+                          faoctasr_stream_t stream) {
+    if (!a || !b || !out) return fail(FAOCTASR_EINVAL, "mean_mix_fwd: null pointer");
+    if (N <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(mean_mix_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a, b, out, La, Lb, wa, wb);
+    return check_launch("mean_mix_fwd");
+}
+
+int faoctasr_mean_mix_bwd(const float* g, float* da, float* db, int N, int La, int Lb, float wa, float wb, faoctasr_stream_t stream) {
+    if (!g) return fail(FAOCTASR_EINVAL, "mean_mix_bwd: null pointer");
+    if (N <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(mean_mix_bwd_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, g, da, db, La, Lb, wa, wb);
+    return check_launch("mean_mix_bwd");
+}
+
+int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, faoctasr_stream_t stream) {
+    if (!p || !g || !m || !v) return fail(FAOCTASR_EINVAL, "adamw_step: null pointer");
+    if (step < 1) return fail(FAOCTASR_EINVAL, "adamw_step: step must be >= 1");
+    if (n <= 0) return FAOCTASR_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
+    return check_launch("adamw");
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""Layer modules over the HIP operators, parameter-compatible with ``torch.nn``.
+
+Parameter / buffer names and shapes equal those of the ``torch.nn`` layers the reference's
+``model.py`` instantiates, so ``state_dict`` keys match and reference ``.pth`` files load
+(checkpoint row).  Class names contain 'Conv' / 'BatchNorm2d' on purpose:
+``utils.weights_init_normal`` dispatches on ``__class__.__name__`` (utils.py:63-69).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # torch.nn.Conv2d default: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias
+        bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size * self.kernel_size)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x, act=None, slope=0.2, reflect_pad=0):
+        if reflect_pad:
+            return ops.conv2d(x, self.weight, self.bias, self.stride, reflect_pad, True, act, slope)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, act, slope)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=%d, stride=%d, padding=%d, bias=%s" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding, self.bias is not None)
+
+
+class ConvTranspose2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.output_padding = kernel_size, stride, padding, output_padding
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        bound = 1.0 / math.sqrt(out_channels * kernel_size * kernel_size)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x, act=None, slope=0.2):
+        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope)
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, act=None, slope=0.2, residual=None):
+        if not self.training:
+            raise NotImplementedError("BatchNorm2d eval mode (running statistics) belongs to the inference path "
+                                      "(SURVEY.md 8f-2) and is not built yet")
+        self.num_batches_tracked += 1
+        return ops.batchnorm_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
+                                   residual)
+
+
+class InstanceNorm2d(nn.Module):
+    """Not used by the reference (model.py:134,184 ignore norm_layer='Instance'); provided because north_star names it."""
+
+    def __init__(self, num_features, eps=1e-5, affine=False):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.weight = nn.Parameter(torch.ones(num_features)) if affine else None
+        self.bias = nn.Parameter(torch.zeros(num_features)) if affine else None
+
+    def forward(self, x, act=None, slope=0.2):
+        return ops.instance_norm(x, self.weight, self.bias, self.eps, act, slope)
+
+
+class ReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    act, slope = "relu", 0.0
+
+    def forward(self, x):
+        return ops.activation(x, "relu")
+
+
+class LeakyReLU(nn.Module):
+    def __init__(self, negative_slope=0.01, inplace=False):
+        super().__init__()
+        self.slope = negative_slope
+
+    act = "lrelu"
+
+    def forward(self, x):
+        return ops.activation(x, "lrelu", self.slope)
+
+
+class Tanh(nn.Module):
+    act, slope = "tanh", 0.0
+
+    def forward(self, x):
+        return ops.activation(x, "tanh")
+
+
+class ReflectionPad2d(nn.Module):
+    """Only exists fused into the following convolution's gather (model.py:450-451,472-473)."""
+
+    def __init__(self, padding):
+        super().__init__()
+        self.padding = padding
+
+    def forward(self, x):
+        raise NotImplementedError("ReflectionPad2d is folded into the next Conv2d by FusedSequential")
+
+
+_ACTS = (ReLU, LeakyReLU, Tanh)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential with the same child indices (hence the same state_dict keys) whose forward
+    runs peephole-fused kernels: [ReflectionPad2d] Conv [act] | BatchNorm [act] | ResBlock [ReLU]."""
+
+    def forward(self, x, start=0):
+        mods = list(self)
+        i, n = start, len(mods)
+        while i < n:
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < n else None
+            if isinstance(m, ReflectionPad2d) and isinstance(nxt, Conv2d) and nxt.padding == 0:
+                after = mods[i + 2] if i + 2 < n else None
+                if isinstance(after, (LeakyReLU, Tanh)):
+                    x = nxt(x, act=after.act, slope=after.slope, reflect_pad=m.padding)
+                    i += 3
+                else:
+                    x = nxt(x, reflect_pad=m.padding)
+                    i += 2
+            elif isinstance(m, (Conv2d, ConvTranspose2d)):
+                if isinstance(nxt, _ACTS):
+                    x = m(x, act=nxt.act, slope=nxt.slope)
+                    i += 2
+                else:
+                    x = m(x)
+                    i += 1
+            elif isinstance(m, (BatchNorm2d, InstanceNorm2d)):
+                if isinstance(nxt, _ACTS):
+                    x = m(x, act=nxt.act, slope=nxt.slope)
+                    i += 2
+                else:
+                    x = m(x)
+                    i += 1
+            elif getattr(m, "is_residual_block", False) and isinstance(nxt, ReLU):
+                x = m(x, post_act="relu")
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x

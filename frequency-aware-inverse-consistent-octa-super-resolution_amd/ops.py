@@ -1,0 +1,594 @@
+"""Autograd operators over the HIP kernels (include/faoctasr.h).
+
+Each ``torch.autograd.Function`` here stands in for one ATen op class the reference's train
+step executes; PyTorch supplies device memory, streams and the autograd tape,
+every arithmetic kernel is ours.  Weight / affine gradients are accumulated by the kernels
+straight into ``param.grad`` when that already exists (the flat gradient arena of
+train.TrainStep), so no per-parameter add kernels run and the all-reduce sees one buffer.
+"""
+import math
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import call, ptr, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+_ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
+
+#: accumulate weight gradients in place into existing ``param.grad`` buffers
+direct_grad = True
+
+
+def act_code(a):
+    return a if isinstance(a, int) else _ACT[a]
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _grad_target(p):
+    g = p.grad
+    if direct_grad and g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g
+    return None
+
+
+# ----------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, slope):
+        x, w = _c(x), _c(w)
+        N, C, IH, IW = x.shape
+        M, Cw, KH, KW = w.shape
+        if Cw != C:
+            raise _lib.KernelError("conv2d: input has %d channels, weight expects %d" % (C, Cw))
+        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+        if OH <= 0 or OW <= 0:
+            raise RuntimeError("Calculated padded input size per channel: (%d x %d). Kernel size: (%d x %d). "
+                               "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
+        y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
+        call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, stream_ptr())
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.w_ref, ctx.b_ref = w, bias
+        ctx.cfg = (stride, pad, reflect, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, reflect, act, slope = ctx.cfg
+        dy = _c(dy)
+        st = stream_ptr()
+        N, C, IH, IW = x.shape
+        M, _, KH, KW = w.shape
+        if act:
+            g = torch.empty_like(dy)
+            call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if reflect:
+                dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
+                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, st)
+                dx = torch.empty_like(x)
+                call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
+            else:
+                dx = torch.empty_like(x)
+                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, st)
+        if ctx.needs_input_grad[1]:
+            tgt = _grad_target(ctx.w_ref)
+            if tgt is None:
+                dw = torch.empty_like(w)
+            call("conv2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
+                 reflect, 1 if tgt is not None else 0, st)
+        if ctx.b_ref is not None and ctx.needs_input_grad[2]:
+            tgt = _grad_target(ctx.b_ref)
+            if tgt is None:
+                db = torch.empty(M, dtype=torch.float32, device=x.device)
+            call("channel_sum", ptr(dy), ptr(tgt if tgt is not None else db), N, M, dy.shape[2] * dy.shape[3],
+                 1 if tgt is not None else 0, st)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, reflect=False, act=None, slope=0.2):
+    return _Conv2d.apply(x, w, bias, int(stride), int(pad), 1 if reflect else 0, act_code(act), float(slope))
+
+
+class _ConvTranspose2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, out_pad, act, slope):
+        x, w = _c(x), _c(w)
+        N, C, IH, IW = x.shape
+        Cw, M, KH, KW = w.shape
+        if Cw != C:
+            raise _lib.KernelError("conv_transpose2d: input has %d channels, weight expects %d" % (C, Cw))
+        OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
+        y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
+        call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
+             stream_ptr())
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.w_ref, ctx.b_ref = w, bias
+        ctx.cfg = (stride, pad, out_pad, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, out_pad, act, slope = ctx.cfg
+        dy = _c(dy)
+        st = stream_ptr()
+        N, C, IH, IW = x.shape
+        _, M, KH, KW = w.shape
+        if act:
+            g = torch.empty_like(dy)
+            call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, st)
+        if ctx.needs_input_grad[1]:
+            tgt = _grad_target(ctx.w_ref)
+            if tgt is None:
+                dw = torch.empty_like(w)
+            call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
+                 out_pad, 1 if tgt is not None else 0, st)
+        if ctx.b_ref is not None and ctx.needs_input_grad[2]:
+            tgt = _grad_target(ctx.b_ref)
+            if tgt is None:
+                db = torch.empty(M, dtype=torch.float32, device=x.device)
+            call("channel_sum", ptr(dy), ptr(tgt if tgt is not None else db), N, M, dy.shape[2] * dy.shape[3],
+                 1 if tgt is not None else 0, st)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=None, slope=0.2):
+    return _ConvTranspose2d.apply(x, w, bias, int(stride), int(pad), int(out_pad), act_code(act), float(slope))
+
+
+# ----------------------------------------------------------------------------------------
+# BatchNorm2d (training statistics) + activation + residual
+# ----------------------------------------------------------------------------------------
+class _BatchNormTrain(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope):
+        x = _c(x)
+        N, C, H, W = x.shape
+        if N * H * W <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+        if residual is not None:
+            residual = _c(residual)
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(x.device, C * 128)
+        call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(stats[0]), ptr(stats[1]),
+             ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr())
+        ctx.save_for_backward(x, gamma, stats, y if act else None)
+        ctx.g_ref, ctx.b_ref = gamma, beta
+        ctx.cfg = (act, slope, residual is not None)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        x, gamma, stats, y = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        dy = _c(dy)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        need_affine = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        tg = tb = dgamma = dbeta = None
+        accumulate = 0
+        if need_affine:
+            tg, tb = _grad_target(ctx.g_ref), _grad_target(ctx.b_ref)
+            if tg is not None and tb is not None:
+                accumulate = 1
+            else:
+                tg = tb = None
+                dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+                dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        dres = None
+        if has_res and ctx.needs_input_grad[3]:
+            dres = torch.empty_like(x) if act else dy
+        ws = _lib.workspace(x.device, C * 128)
+        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(dx),
+             ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
+             N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def batchnorm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=None, slope=0.2, residual=None):
+    y, _ = _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), act_code(act), float(slope))
+    return y
+
+
+class _InstanceNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, slope):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2, N * C), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(x.device, N * C * 128)
+        call("instancenorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats[0]), ptr(stats[1]), N, C, H * W, eps, act, slope,
+             ptr(ws), stream_ptr())
+        ctx.save_for_backward(x, gamma, stats, y if act else None)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats, y = ctx.saved_tensors
+        act, slope = ctx.cfg
+        dy = _c(dy)
+        N, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        ws = _lib.workspace(x.device, N * C * 128)
+        call("instancenorm_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(dx), ptr(dgamma), ptr(dbeta),
+             N, C, H * W, act, slope, ptr(ws), stream_ptr())
+        return dx, dgamma, dbeta, None, None, None
+
+
+def instance_norm(x, gamma=None, beta=None, eps=1e-5, act=None, slope=0.2):
+    return _InstanceNorm.apply(x, gamma, beta, float(eps), act_code(act), float(slope))
+
+
+# ----------------------------------------------------------------------------------------
+# pointwise
+# ----------------------------------------------------------------------------------------
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("act_fwd", ptr(x), ptr(y), x.numel(), act, slope, stream_ptr())
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        call("act_bwd", ptr(dy), ptr(y), ptr(dx), dy.numel(), ctx.cfg[0], ctx.cfg[1], stream_ptr())
+        return dx, None, None
+
+
+def activation(x, act, slope=0.2):
+    return _Act.apply(x, act_code(act), float(slope))
+
+
+class _Cat2Act(Function):
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        a, b = _c(a), _c(b)
+        N, Ca, H, W = a.shape
+        Cb = b.shape[1]
+        y = torch.empty((N, Ca + Cb, H, W), dtype=torch.float32, device=a.device)
+        call("cat2_act_fwd", ptr(a), ptr(b), ptr(y), N, Ca, Cb, H * W, act, slope, stream_ptr())
+        ctx.save_for_backward(y if act else None)
+        ctx.cfg = (act, slope, Ca, Cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope, Ca, Cb = ctx.cfg
+        dy = _c(dy)
+        N, _, H, W = dy.shape
+        da = torch.empty((N, Ca, H, W), dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        db = torch.empty((N, Cb, H, W), dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
+        call("cat2_act_bwd", ptr(dy), ptr(y), ptr(da), ptr(db), N, Ca, Cb, H * W, act, slope, stream_ptr())
+        return da, db, None, None
+
+
+def cat2_act(a, b, act=None, slope=0.2):
+    """torch.cat([a, b], 1) followed by an activation (model.py:266+249, 268+431, 298+431)."""
+    return _Cat2Act.apply(a, b, act_code(act), float(slope))
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        call("axpby", ptr(a), ptr(b), ptr(y), a.numel(), 1.0, 1.0, stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = _c(a), _c(b)
+        y = torch.empty_like(a)
+        call("axpby", ptr(a), ptr(b), ptr(y), a.numel(), alpha, beta, stream_ptr())
+        ctx.cfg = (alpha, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        alpha, beta = ctx.cfg
+        dy = _c(dy)
+        st = stream_ptr()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(dy)
+            call("axpby", ptr(dy), ptr(dy), ptr(da), dy.numel(), alpha, 0.0, st)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(dy)
+            call("axpby", ptr(dy), ptr(dy), ptr(db), dy.numel(), beta, 0.0, st)
+        return da, db, None, None
+
+
+def axpby(a, b, alpha, beta):
+    return _Axpby.apply(a, b, float(alpha), float(beta))
+
+
+# ----------------------------------------------------------------------------------------
+# Haar DWT
+# ----------------------------------------------------------------------------------------
+class _HaarAFB2D(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, C, H, W = x.shape
+        ll = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        hi = torch.empty((N, C, 3, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        call("haar_dwt2d_fwd", ptr(x), ptr(ll), ptr(hi), N * C, H, W, stream_ptr())
+        ctx.shape = (N, C, H, W)
+        return ll, hi
+
+    @staticmethod
+    def backward(ctx, dll, dhi):
+        N, C, H, W = ctx.shape
+        dx = torch.empty((N, C, H, W), dtype=torch.float32, device=(dll if dll is not None else dhi).device)
+        call("haar_dwt2d_bwd", ptr(_c(dll)) if dll is not None else None, ptr(_c(dhi)) if dhi is not None else None, ptr(dx), N * C, H, W,
+             stream_ptr())
+        return dx
+
+
+class _HaarSFB2D(Function):
+    @staticmethod
+    def forward(ctx, ll, hi):
+        ll, hi = _c(ll), _c(hi)
+        N, C, h, w = ll.shape
+        x = torch.empty((N, C, 2 * h, 2 * w), dtype=torch.float32, device=ll.device)
+        call("haar_dwt2d_bwd", ptr(ll), ptr(hi), ptr(x), N * C, 2 * h, 2 * w, stream_ptr())
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = _c(dx)
+        N, C, H, W = dx.shape
+        dll = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=dx.device)
+        dhi = torch.empty((N, C, 3, H // 2, W // 2), dtype=torch.float32, device=dx.device)
+        call("haar_dwt2d_fwd", ptr(dx), ptr(dll), ptr(dhi), N * C, H, W, stream_ptr())
+        return dll, dhi
+
+
+def haar_afb2d(x):
+    return _HaarAFB2D.apply(x)
+
+
+def haar_sfb2d(ll, hi):
+    return _HaarSFB2D.apply(ll, hi)
+
+
+class _HaarDFront(Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _c(x)
+        N, C, H, W = x.shape
+        if C != 1:
+            raise _lib.KernelError("discriminator front end expects single-channel images")
+        y = torch.empty((N, 3 if mode else 1, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        call("haar_dfront_fwd", ptr(x), ptr(y), N, H, W, mode, stream_ptr())
+        ctx.cfg = (N, H, W, mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, mode = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((N, 1, H, W), dtype=torch.float32, device=dy.device)
+        call("haar_dfront_bwd", ptr(dy), ptr(dx), N, H, W, mode, stream_ptr())
+        return dx, None
+
+
+def haar_dfront(x, mode):
+    """mode 0: LL (FS_DiscriminatorA, model.py:171-172); 1: cat(LH,HL,HH)*0.5+0.5 (FS_DiscriminatorB, model.py:225-233)."""
+    return _HaarDFront.apply(x, int(mode))
+
+
+# ----------------------------------------------------------------------------------------
+# FFT Gaussian split as circulant GEMMs
+# ----------------------------------------------------------------------------------------
+_circ_cache = {}
+
+
+def circulant_lowpass(n, radius, device):
+    """Real symmetric circulant C with C x == ifft(ifftshift(g) * fft(x)) for the centred Gaussian taps
+    g[k] = exp(-(k - int(n/2))^2 / (2 r^2)) of utils.py:71-80 (the 2-D mask is the outer product g g^T)."""
+    key = (n, float(radius), str(device))
+    c = _circ_cache.get(key)
+    if c is None:
+        k = np.arange(n)
+        taps = np.exp(-0.5 * (k - int(n / 2)) ** 2 / float(radius) ** 2)
+        col = np.real(np.fft.ifft(np.fft.ifftshift(taps)))
+        mat = col[(k[:, None] - k[None, :]) % n]
+        c = torch.from_numpy(mat.astype(np.float32)).to(device).contiguous()
+        _circ_cache[key] = c
+    return c
+
+
+def _lowpass2d(x3, ch, cw, st):
+    """x3: (B,H,W) -> Ch @ x_b @ Cw for every b (two MFMA SGEMM launches)."""
+    B, H, W = x3.shape
+    t = torch.empty_like(x3)
+    call("sgemm_batched", ptr(x3), ptr(cw), ptr(t), B * H, W, W, W, W, W, 0, 0, 0, 1, st)
+    y = torch.empty_like(x3)
+    call("sgemm_batched", ptr(ch), ptr(t), ptr(y), H, W, H, H, W, W, 0, H * W, H * W, B, st)
+    return y
+
+
+class _FreqSplit(Function):
+    @staticmethod
+    def forward(ctx, x, r_hp, r_lp):
+        x = _c(x)
+        B, C, H, W = x.shape
+        dev = x.device
+        mats = (circulant_lowpass(H, r_hp, dev), circulant_lowpass(W, r_hp, dev), circulant_lowpass(H, r_lp, dev), circulant_lowpass(W, r_lp, dev))
+        st = stream_ptr()
+        x3 = x.view(B * C, H, W)
+        low_hp = _lowpass2d(x3, mats[0], mats[1], st)
+        low_lp = _lowpass2d(x3, mats[2], mats[3], st)
+        hf, lf = torch.empty_like(x), torch.empty_like(x)
+        call("freq_mix_fwd", ptr(x), ptr(low_hp), ptr(low_lp), ptr(hf), ptr(lf), x.numel(), st)
+        ctx.save_for_backward(x, low_hp, low_lp)
+        ctx.mats = mats
+        return hf, lf
+
+    @staticmethod
+    def backward(ctx, g_hf, g_lf):
+        x, low_hp, low_lp = ctx.saved_tensors
+        mats = ctx.mats
+        st = stream_ptr()
+        B, C, H, W = x.shape
+        s_hp, s_lp, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        call("freq_mix_bwd", ptr(x), ptr(low_hp), ptr(low_lp), ptr(_c(g_hf)) if g_hf is not None else None,
+             ptr(_c(g_lf)) if g_lf is not None else None, ptr(s_hp), ptr(s_lp), ptr(dx), x.numel(), st)
+        # the circulants are symmetric, so the adjoint of x -> Ch x Cw is the same map
+        a = _lowpass2d(s_hp.view(B * C, H, W), mats[0], mats[1], st)
+        b = _lowpass2d(s_lp.view(B * C, H, W), mats[2], mats[3], st)
+        n = x.numel()
+        call("axpby", ptr(dx), ptr(a), ptr(dx), n, 1.0, -1.0, st)
+        call("axpby", ptr(dx), ptr(b), ptr(dx), n, 1.0, 1.0, st)
+        return dx, None, None
+
+
+def freq_split(x, r_hp, r_lp):
+    """hf = (high_pass(x_b, r_hp) + x_b)/2, lf = low_pass(x_b, r_lp) per sample (train.py:173-175)."""
+    return _FreqSplit.apply(x, float(r_hp), float(r_lp))
+
+
+# ----------------------------------------------------------------------------------------
+# losses and the discriminator head
+# ----------------------------------------------------------------------------------------
+LOSS_MSE, LOSS_L1, LOSS_BCE_LOGITS = 0, 1, 2
+
+
+class _Loss(Function):
+    @staticmethod
+    def forward(ctx, a, b, kind, scale):
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise _lib.KernelError("loss operands differ in shape: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = _lib.workspace(a.device, 1024)
+        call("loss_fwd", ptr(a), ptr(b), ptr(out), a.numel(), kind, scale, ptr(ws), stream_ptr())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (kind, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        kind, scale = ctx.cfg
+        g = _c(g)
+        da = db = None
+        st = stream_ptr()
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            call("loss_bwd", ptr(a), ptr(b), ptr(g), ptr(da), a.numel(), kind, scale, 0, st)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            call("loss_bwd", ptr(a), ptr(b), ptr(g), ptr(db), a.numel(), kind, scale, 1, st)
+        return da, db, None, None
+
+
+def mse_loss(a, b, weight=1.0):
+    return _Loss.apply(a, b, LOSS_MSE, float(weight) / a.numel())
+
+
+def l1_loss(a, b, weight=1.0):
+    return _Loss.apply(a, b, LOSS_L1, float(weight) / a.numel())
+
+
+def bce_with_logits(inp, target, weight=1.0):
+    """torch.nn.BCEWithLogitsLoss()(inp, target); the gradient w.r.t. ``target`` is -inp/N (train.py:230-231)."""
+    return _Loss.apply(inp, target, LOSS_BCE_LOGITS, float(weight) / inp.numel())
+
+
+class _MeanMix(Function):
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        a, b = _c(a), _c(b)
+        N = a.shape[0]
+        La, Lb = a.numel() // N, b.numel() // N
+        out = torch.empty(N, dtype=torch.float32, device=a.device)
+        call("mean_mix_fwd", ptr(a), ptr(b), ptr(out), N, La, Lb, wa, wb, stream_ptr())
+        ctx.cfg = (a.shape, b.shape, wa, wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sa, sb, wa, wb = ctx.cfg
+        g = _c(g)
+        N = sa[0]
+        da = torch.empty(sa, dtype=torch.float32, device=g.device)
+        db = torch.empty(sb, dtype=torch.float32, device=g.device)
+        call("mean_mix_bwd", ptr(g), ptr(da), ptr(db), N, da.numel() // N, db.numel() // N, wa, wb, stream_ptr())
+        return da, db, None, None
+
+
+def mean_mix(a, b, wa=0.7, wb=0.3):
+    """flatten(wa * global_avg_pool(a) + wb * global_avg_pool(b)) -- model.py:158-164."""
+    return _MeanMix.apply(a, b, float(wa), float(wb))
+
+
+# ----------------------------------------------------------------------------------------
+# SSIM
+# ----------------------------------------------------------------------------------------
+class _SSIM(Function):
+    @staticmethod
+    def forward(ctx, a, b, size_average):
+        a, b = _c(a), _c(b)
+        N, C, H, W = a.shape
+        sums = torch.empty(N, dtype=torch.float32, device=a.device)
+        call("ssim_fwd", ptr(a), ptr(b), ptr(sums), N, C, H, W, stream_ptr())
+        ctx.save_for_backward(a, b)
+        ctx.size_average = size_average
+        # the final division of N (or 1) numbers is host-side plumbing on a tiny tensor
+        return sums.sum() / (N * C * H * W) if size_average else sums / (C * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        N, C, H, W = a.shape
+        g = _c(g).reshape(-1)
+        scale = 1.0 / (N * C * H * W) if ctx.size_average else 1.0 / (C * H * W)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call("ssim_bwd", ptr(a), ptr(b), ptr(g), g.numel(), scale, ptr(da), ptr(db), N, C, H, W, stream_ptr())
+        return da, db, None
+
+
+def ssim(a, b, size_average=True):
+    return _SSIM.apply(a, b, bool(size_average))

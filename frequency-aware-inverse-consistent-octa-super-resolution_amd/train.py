@@ -1,0 +1,195 @@
+"""The train step of the reference (train.py:166-269) as a driver over the HIP operators.
+
+``TrainStep`` owns what the reference script builds at module level (train.py:73-126): the four
+networks, the two AdamW optimizers (as two flat fp32 arenas: parameters, gradients and both
+moments of every *live* tensor are contiguous, so the optimizer is one kernel launch and the
+data-parallel exchange is one all-reduce per phase), the targets and the replay buffers.
+``step(real_A, real_B)`` is one loop-body iteration.  The only semantic extension is the batched
+per-sample frequency split (the reference supports batch 1 only: SURVEY.md fact 3).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import call, ptr, stream_ptr
+from .model import FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A
+from .utils import ReplayBuffer, set_requires_grad, weights_init_normal
+from .wavelets import DWTForward
+
+# parameters that exist in the reference's state_dict but never receive a gradient
+# (model.py:241,254-257: unet/unet_up of NetworkA2B; model.py:281-284: skip of NetworkB2A);
+# torch.optim.AdamW skips them because their .grad stays None
+DEAD_PREFIXES = {"NetworkA2B": ("unet.", "unet_up."), "NetworkB2A": ("skip.",)}
+
+
+def live_parameters(net):
+    dead = DEAD_PREFIXES.get(type(net).__name__, ())
+    return [(n, p) for n, p in net.named_parameters() if not n.startswith(dead)]
+
+
+class ParamArena:
+    """Flat fp32 storage for a parameter group: ``param.data`` and ``param.grad`` become views of two
+    contiguous buffers; AdamW moments live beside them.  Layout: tensors in registration order, each
+    start aligned to 4 floats (16 B) so every view is float4-addressable."""
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.numel = total
+        self.live_numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = offs
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat[o:o + p.numel()].view(p.shape)
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # re-attach in case something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def all_reduce(self, group=None):
+        """Sum gradients over ranks (RCCL when the tensors live on a GPU); the 1/world average is folded
+        into the AdamW kernel's grad_scale."""
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        call("adamw_step", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, self.lr, self.betas[0],
+             self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream_ptr())
+
+
+class TrainStep:
+    def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
+                 beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
+                 process_group=None, distributed=None, init=True):
+        dev = torch.device(device)
+        made = netG_A2B is None
+        self.netG_A2B = (netG_A2B or NetworkA2B()).to(dev)            # train.py:73-76
+        self.netG_B2A = (netG_B2A or NetworkB2A()).to(dev)
+        self.netD_A = (netD_A or FS_DiscriminatorA(1)).to(dev)
+        self.netD_B = (netD_B or FS_DiscriminatorB(1)).to(dev)
+        if made and init:                                             # train.py:84-88
+            for n in (self.netG_A2B, self.netG_B2A, self.netD_A, self.netD_B):
+                n.apply(weights_init_normal)
+        self.w = dict(beta1=beta1, beta2=beta2, beta3=beta3, beta4=beta4, beta5=beta5)     # train.py:50-54
+        self.ssim_weight, self.whf_weight, self.dwt_levels = ssim_weight, whf_weight, dwt_levels
+        self.dwt_loss = DWTForward(J=dwt_levels, wave="haar", mode="reflect").to(dev) if whf_weight else None
+        # train.py:102-103: one AdamW per side, lr 1.3e-4, betas (0.9, 0.999), default eps/weight_decay
+        self.opt_G = ParamArena(live_parameters(self.netG_A2B) + live_parameters(self.netG_B2A), lr, betas)
+        self.opt_D = ParamArena(live_parameters(self.netD_A) + live_parameters(self.netD_B), lr, betas)
+        self.fake_A_buffer, self.fake_B_buffer = ReplayBuffer(), ReplayBuffer()         # train.py:125-126
+        self.group = process_group
+        self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self._targets = {}
+        self.device = dev
+
+    # -- pieces of the loop body ---------------------------------------------------------
+    def targets(self, B):
+        t = self._targets.get(B)
+        if t is None:
+            t = (torch.ones(B, device=self.device), torch.zeros(B, device=self.device))     # train.py:119-123
+            self._targets[B] = t
+        return t
+
+    def forward_generators(self, real_A, real_B):
+        """train.py:173-214."""
+        G_A2B, G_B2A = self.netG_A2B, self.netG_B2A
+        o = {}
+        hf, lf = ops.freq_split(real_A, 10, 8)
+        _, hf_feature_A, o["fake_B"] = G_A2B(lf, hf)
+        _, _, o["idt_A"] = G_B2A(hf, lf)
+        o["hf_feature_A"] = hf_feature_A.detach()
+        hf, lf = ops.freq_split(o["fake_B"], 5, 14)
+        o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)
+        hf, lf = ops.freq_split(real_B, 5, 14)
+        hf_feature_B, _, o["fake_A"] = G_B2A(hf, lf)
+        _, _, o["idt_B"] = G_A2B(lf, hf)
+        o["hf_feature_B"] = hf_feature_B.detach()
+        hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)
+        return o
+
+    def generator_loss(self, o, real_A, real_B):
+        """train.py:221-236 (+ the opt-in SSIM term of the commented line train.py:234 and a wavelet-HF L1 term)."""
+        w = self.w
+        ones, _ = self.targets(real_A.shape[0])
+        L = {}
+        L["loss_GAN_A2B"] = ops.mse_loss(self.netD_B(o["fake_B"]), ones, w["beta4"])
+        L["loss_GAN_B2A"] = ops.mse_loss(self.netD_A(o["fake_A"]), ones, w["beta5"])
+        L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
+        L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
+            ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
+        L["loss_idt"] = ops.l1_loss(real_A, o["idt_A"], w["beta2"]) + ops.l1_loss(real_B, o["idt_B"], w["beta2"])
+        total = L["loss_GAN_A2B"] + L["loss_GAN_B2A"] + L["loss_cycle_ABA"] + L["loss_cycle_BAB"] + L["loss_idt"]
+        if self.ssim_weight:
+            L["loss_ssim"] = self.ssim_weight * ((1 - ops.ssim(o["recovered_A"], real_A)) + (1 - ops.ssim(o["recovered_B"], real_B)))
+            total = total + L["loss_ssim"]
+        if self.whf_weight:
+            t = 0
+            for rec, real in ((o["recovered_A"], real_A), (o["recovered_B"], real_B)):
+                _, yh_r = self.dwt_loss(rec)
+                _, yh_t = self.dwt_loss(real)
+                for a, b in zip(yh_r, yh_t):
+                    t = t + ops.l1_loss(a, b, self.whf_weight)
+            L["loss_whf"] = t
+            total = total + t
+        L["loss_G"] = total
+        return L
+
+    def step(self, real_A, real_B, sync=False, keep=False):
+        """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats)."""
+        B = real_A.shape[0]
+        ones, zeros = self.targets(B)
+        o = self.forward_generators(real_A, real_B)
+        # (2) generators, train.py:218-239
+        set_requires_grad([self.netD_A, self.netD_B], False)
+        self.opt_G.zero_grad()
+        L = self.generator_loss(o, real_A, real_B)
+        L["loss_G"].backward()
+        if self.distributed:
+            self.opt_G.all_reduce(self.group)
+        self.opt_G.step(1.0 / self.world)
+        # (3) discriminators, train.py:242-269
+        set_requires_grad([self.netD_A, self.netD_B], True)
+        self.opt_D.zero_grad()
+        fake_A = self.fake_A_buffer.push_and_pop(o["fake_A"])
+        L["loss_D_A"] = ops.mse_loss(self.netD_A(real_A), ones, 0.5) + ops.mse_loss(self.netD_A(fake_A.detach()), zeros, 0.5)
+        L["loss_D_A"].backward()
+        fake_B = self.fake_B_buffer.push_and_pop(o["fake_B"])
+        L["loss_D_B"] = ops.mse_loss(self.netD_B(real_B), ones, 0.5) + ops.mse_loss(self.netD_B(fake_B.detach()), zeros, 0.5)
+        L["loss_D_B"].backward()
+        if self.distributed:
+            self.opt_D.all_reduce(self.group)
+        self.opt_D.step(1.0 / self.world)
+        out = {k: v.detach() for k, v in L.items()}
+        if sync:
+            out = {k: float(v) for k, v in out.items()}
+        if keep:
+            out["tensors"] = {k: v.detach() for k, v in o.items()}
+        return out
+
+    def grad_norms(self):
+        """Per-network gradient L2 norms (diagnostics / parity tests; host-side reduction)."""
+        r = {}
+        for name, net in (("A2B", self.netG_A2B), ("B2A", self.netG_B2A), ("D_A", self.netD_A), ("D_B", self.netD_B)):
+            sq = 0.0
+            for _, p in live_parameters(net):
+                if p.grad is not None:
+                    sq += float((p.grad.double() ** 2).sum())
+            r[name] = sq ** 0.5
+        return r

@@ -1,0 +1,169 @@
+/*
+ * faoctasr.h -- C ABI of the MI355X (gfx950) kernels behind the frequency-aware OCTA
+ * super-resolution train step.
+ *
+ * The reference has no native code: its hot path (train.py:166-269) runs stock ATen
+ * ops from Python.  These entry points are what a binding for that path would bind,
+ * one per ATen op class the path executes.  Conventions:
+ *   - every tensor is a raw DEVICE pointer to contiguous fp32 NCHW data owned by the caller;
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued: no allocation,
+ *     no synchronisation, no host read-back (safe under hipGraph capture);
+ *   - workspaces are caller-provided (sizes from the *_workspace_floats queries);
+ *   - return 0 on success, negative on error; faoctasr_last_error() gives the thread-local text.
+ * Each function cites the reference call site(s) it stands in for (paths under /root/reference).
+ */
+#ifndef FAOCTASR_H
+#define FAOCTASR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* faoctasr_stream_t;
+
+enum { FAOCTASR_ACT_NONE = 0, FAOCTASR_ACT_RELU = 1, FAOCTASR_ACT_LRELU = 2, FAOCTASR_ACT_TANH = 3 };
+enum { FAOCTASR_OK = 0, FAOCTASR_EINVAL = -1, FAOCTASR_EUNSUPPORTED = -2, FAOCTASR_EHIP = -3 };
+
+int faoctasr_version(void);
+const char* faoctasr_last_error(void);
+
+/* ---- convolution family (implicit GEMM on f32 MFMA) --------------------------------------
+ * nn.Conv2d forward: model.py:102,109,117,122 (discriminator), 242-244,250,258,275-277,286
+ * (stems/skip), 412-414,438 (ResnetBlock, head), 451,458,473 (ResnetGenerator), 494,499.
+ * y[N,M,OH,OW] = act(conv(x[N,C,IH,IW], w[M,C,KH,KW]) + bias); OH=(IH+2*pad-KH)/stride+1.
+ * reflect!=0 folds nn.ReflectionPad2d(pad) (model.py:450,472) into the gather.          */
+int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                        int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                        int reflect, int act, float slope, faoctasr_stream_t stream);
+/* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
+ * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with
+ * faoctasr_reflect_pad_bwd).                                                              */
+int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx,
+                          int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                          faoctasr_stream_t stream);
+/* aten::convolution_backward, weight gradient.  dw[M,C,KH,KW] is overwritten, or added to
+ * when accumulate != 0 (the gradient arena is zeroed once per step instead).              */
+int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                          int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                          int reflect, int accumulate, faoctasr_stream_t stream);
+/* nn.ConvTranspose2d forward: model.py:431 (4x4 s2 p1), 469 (3x3 s2 p1 output_padding 1).
+ * x[N,C,IH,IW], w[C,M,KH,KW], y[N,M,OH,OW], OH=(IH-1)*stride-2*pad+KH+out_pad.          */
+int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                                  int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                                  int out_pad, int act, float slope, faoctasr_stream_t stream);
+int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx,
+                                    int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                                    int out_pad, faoctasr_stream_t stream);
+int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw,
+                                    int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                                    int out_pad, int accumulate, faoctasr_stream_t stream);
+/* gradient of nn.ReflectionPad2d(p): dx[NC,H,W] += fold of dxp[NC,H+2p,W+2p] (dx overwritten) */
+int faoctasr_reflect_pad_bwd(const float* dxp, float* dx, int NC, int H, int W, int p, faoctasr_stream_t stream);
+/* per-channel sum over (N,HW): conv bias gradient.  db[C] overwritten (or added to).      */
+int faoctasr_channel_sum(const float* dy, float* db, int N, int C, int HW, int accumulate, faoctasr_stream_t stream);
+
+/* ---- BatchNorm2d (training mode) + fused activation / residual ----------------------------
+ * nn.BatchNorm2d calls: model.py:110,118 (D), 244-245,251 (stems/skip), 412-414,431 (shallowNet),
+ * 452,459,470 (ResnetGenerator), 494,499 (ResidualBlock).  Batch statistics over (N,H,W),
+ * biased variance for normalisation, unbiased for running_var, momentum/eps as given.
+ * y = act(gamma*xhat + beta + residual)   (residual may be NULL).
+ * workspace: faoctasr_bn_workspace_floats(C) floats.                                       */
+long faoctasr_bn_workspace_floats(int C);
+int faoctasr_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                                 float* y, float* save_mean, float* save_invstd,
+                                 float* running_mean, float* running_var,
+                                 int N, int C, int HW, float eps, float momentum, int act, float slope,
+                                 float* workspace, faoctasr_stream_t stream);
+/* dx overwritten; dgamma[C], dbeta[C] overwritten or (accumulate_affine != 0) added to; y is
+ * the saved forward output (activation mask); the residual gradient dy*act'(y) is written to
+ * dres when dres != NULL.                                                                 */
+int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+                                 const float* save_mean, const float* save_invstd,
+                                 float* dx, float* dgamma, float* dbeta, float* dres,
+                                 int N, int C, int HW, int act, float slope, int accumulate_affine,
+                                 float* workspace, faoctasr_stream_t stream);
+/* InstanceNorm2d (named by north_star; not on the reference's path): per-(n,c) statistics;
+ * save_mean/save_invstd have N*C entries, workspace faoctasr_bn_workspace_floats(N*C) floats. */
+int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                              float* save_mean, float* save_invstd, int N, int C, int HW, float eps,
+                              int act, float slope, float* workspace, faoctasr_stream_t stream);
+int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+                              const float* save_mean, const float* save_invstd, float* dx,
+                              float* dgamma, float* dbeta, int N, int C, int HW, int act, float slope,
+                              float* workspace, faoctasr_stream_t stream);
+
+/* ---- pointwise / data movement ----------------------------------------------------------- */
+/* nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh (model.py:102,111,119,243,249,254,413,431,438,...) */
+int faoctasr_act_fwd(const float* x, float* y, long n, int act, float slope, faoctasr_stream_t stream);
+/* dx = dy * act'(y) with y the activation OUTPUT */
+int faoctasr_act_bwd(const float* dy, const float* y, float* dx, long n, int act, float slope, faoctasr_stream_t stream);
+/* torch.cat([a,b],1) followed by an optional activation (model.py:266,268,298 + 249,431) */
+int faoctasr_cat2_act_fwd(const float* a, const float* b, float* y, int N, int Ca, int Cb, int HW,
+                          int act, float slope, faoctasr_stream_t stream);
+int faoctasr_cat2_act_bwd(const float* dy, const float* y, float* da, float* db, int N, int Ca, int Cb, int HW,
+                          int act, float slope, faoctasr_stream_t stream);
+/* y = alpha*a + beta*b (residual add x + conv_block(x): model.py:420,505) */
+int faoctasr_axpby(const float* a, const float* b, float* y, long n, float alpha, float beta, faoctasr_stream_t stream);
+
+/* ---- Haar DWT / IDWT, mode 'reflect', even H and W ----------------------------------------
+ * DWTForward.forward transform2d.py:44-74 -> AFB2D lowlevel.py:312-365; DWTInverse.forward
+ * transform2d.py:111-148 -> SFB2D lowlevel.py:647-694.  One level per call.
+ * x[NC,H,W] -> ll[NC,H/2,W/2], hi[NC,3,H/2,W/2] (band order LH,HL,HH).                     */
+int faoctasr_haar_dwt2d_fwd(const float* x, float* ll, float* hi, long NC, int H, int W, faoctasr_stream_t stream);
+/* AFB2D.backward lowlevel.py:349-365 (= synthesis): dx[NC,H,W] from dll, dhi (either may be NULL = zeros) */
+int faoctasr_haar_dwt2d_bwd(const float* dll, const float* dhi, float* dx, long NC, int H, int W, faoctasr_stream_t stream);
+/* fused discriminator front ends: model.py:166-179 (D_A: LL only) and model.py:222-235
+ * (D_B: cat(LH,HL,HH)*0.5+0.5, x[N,1,H,W] -> y[N,3,H/2,W/2]); mode 0 = LL, 1 = cat-normalised */
+int faoctasr_haar_dfront_fwd(const float* x, float* y, int N, int H, int W, int mode, faoctasr_stream_t stream);
+int faoctasr_haar_dfront_bwd(const float* dy, float* dx, int N, int H, int W, int mode, faoctasr_stream_t stream);
+
+/* ---- FFT Gaussian frequency split as circulant GEMMs ---------------------------------------
+ * utils.high_pass / utils.low_pass (utils.py:71-117) as called at train.py:173-175,189-191,
+ * 197-199,211-213.  The shifted Gaussian mask is separable, so ifft2(mask*fft2(x)) = Ch x Cw^T
+ * with real symmetric circulant matrices built once per (n, radius) by the host.
+ * Batched row-major SGEMM on f32 MFMA: for b in [0,batch): C_b = A_b(MxK) * B_b(KxN).         */
+int faoctasr_sgemm_batched(const float* A, const float* B, float* C, int M, int N, int K,
+                           int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int batch,
+                           faoctasr_stream_t stream);
+/* hf = (|x - low_hp| + x)/2, lf = -|low_lp|  (train.py:173-175) */
+int faoctasr_freq_mix_fwd(const float* x, const float* low_hp, const float* low_lp, float* hf, float* lf,
+                          long n, faoctasr_stream_t stream);
+/* s_hp = 0.5*g_hf*sign(x-low_hp), s_lp = -g_lf*sign(low_lp), dx_direct = 0.5*g_hf + s_hp
+ * (the caller then subtracts Ch s_hp Cw and adds Ch s_lp Cw)                                */
+int faoctasr_freq_mix_bwd(const float* x, const float* low_hp, const float* low_lp, const float* g_hf, const float* g_lf,
+                          float* s_hp, float* s_lp, float* dx_direct, long n, faoctasr_stream_t stream);
+
+/* ---- SSIM (ssim.py:17-37), fused separable 11-tap Gaussian window, zero padding -------------
+ * per-image sums of the ssim map are written to sums[N] (mean = sums/(C*H*W)).              */
+int faoctasr_ssim_fwd(const float* a, const float* b, float* sums, int N, int C, int H, int W, faoctasr_stream_t stream);
+/* da, db (either may be NULL) = g[n or 0] * d(sum of map)/d(a|b); gscale multiplies, g is a device scalar
+ * array of length gN (1 = shared) */
+int faoctasr_ssim_bwd(const float* a, const float* b, const float* g, int gN, float gscale, float* da, float* db,
+                      int N, int C, int H, int W, faoctasr_stream_t stream);
+
+/* ---- losses (train.py:91-99) -----------------------------------------------------------------
+ * kind 0: sum (a-b)^2 (MSELoss), 1: sum |a-b| (L1Loss), 2: BCEWithLogits(input=a, target=b) sum.
+ * out[0] = scale * sum (overwritten); workspace: faoctasr_loss_workspace_floats() floats.  */
+long faoctasr_loss_workspace_floats(void);
+int faoctasr_loss_fwd(const float* a, const float* b, float* out, long n, int kind, float scale, float* workspace,
+                      faoctasr_stream_t stream);
+/* gradient wrt `wrt` (0 = a, 1 = b): d = g[0]*scale * dloss/d(...) ; g is a device scalar */
+int faoctasr_loss_bwd(const float* a, const float* b, const float* g, float* d, long n, int kind, float scale, int wrt,
+                      faoctasr_stream_t stream);
+/* discriminator head model.py:158-164: out[n] = wa*mean(a[n,:]) + wb*mean(b[n,:]) */
+int faoctasr_mean_mix_fwd(const float* a, const float* b, float* out, int N, int La, int Lb, float wa, float wb,
+                          faoctasr_stream_t stream);
+int faoctasr_mean_mix_bwd(const float* g, float* da, float* db, int N, int La, int Lb, float wa, float wb,
+                          faoctasr_stream_t stream);
+
+/* ---- optimizer: torch.optim.AdamW step (train.py:102-103,239,269) over one flat arena -------- */
+int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, float grad_scale, faoctasr_stream_t stream);
+
+/* ---- utility ---------------------------------------------------------------------------------- */
+int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAOCTASR_H */

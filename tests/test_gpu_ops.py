@@ -1,0 +1,392 @@
+"""GPU parity: every HIP operator (through the C ABI / ctypes) against the CPU oracle or a plain
+torch-CPU fp32 statement of the same op, and against the golden fixtures captured from the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import faoctasr
+    faoctasr._lib.load()
+    return faoctasr
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import octa_oracle
+    return octa_oracle
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+CONV_CASES = [
+    # N, C, H, W, M, k, stride, pad, reflect, bias, act
+    (2, 1, 32, 32, 64, 4, 2, 1, False, False, "lrelu"),       # c1 stem
+    (2, 64, 24, 40, 128, 3, 1, 1, False, False, None),        # c2
+    (1, 16, 20, 24, 24, 7, 1, 3, True, True, None),           # c3 reflect 7x7 + bias
+    (2, 64, 16, 16, 128, 3, 2, 1, False, False, None),        # c4
+    (2, 256, 8, 8, 256, 3, 1, 1, False, False, None),         # c5
+    (2, 64, 16, 16, 1, 3, 1, 1, False, False, "tanh"),        # c9
+    (2, 3, 32, 32, 64, 4, 2, 1, False, True, "lrelu"),        # d1 (3-ch dwt branch)
+    (3, 128, 8, 8, 256, 4, 2, 1, False, True, None),          # d2
+    (2, 512, 4, 4, 512, 4, 1, 1, False, True, None),          # d3 (4 -> 3)
+    (2, 512, 3, 3, 1, 4, 1, 1, False, True, None),            # d3 last (3 -> 2)
+    (1, 5, 9, 11, 7, 3, 2, 1, False, True, "relu"),           # ragged odd sizes
+    (1, 8, 192 // 8, 192 // 8, 130, 3, 1, 1, False, False, None),   # M not a tile multiple
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(fa, case):
+    N, C, H, W, M, k, s, p, reflect, bias, act = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(M, C, k, k, generator=g) * 0.05
+    b = torch.randn(M, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    xin = F.pad(xr, (p, p, p, p), mode="reflect") if reflect else xr
+    ref = F.conv2d(xin, wr, br, stride=s, padding=0 if reflect else p)
+    if act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    elif act == "tanh":
+        ref = torch.tanh(ref)
+    elif act == "relu":
+        ref = F.relu(ref)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd, wd = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    bd = dev(b).requires_grad_(True) if bias else None
+    out = fa.ops.conv2d(xd, wd, bd, s, p, reflect, act, 0.2)
+    assert out.shape == ref.shape
+    close(out, ref, rtol=2e-4, atol=2e-5)
+    out.backward(dev(cot))
+    assert rel_l2(xd.grad, xr.grad) < 2e-5
+    assert rel_l2(wd.grad, wr.grad) < 2e-5
+    close(xd.grad, xr.grad, rtol=1e-3, atol=1e-4)
+    close(wd.grad, wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+    if bias:
+        close(bd.grad, br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+
+
+CONVT_CASES = [
+    # N, C, H, W, M, k, stride, pad, out_pad, bias
+    (2, 128, 12, 12, 64, 4, 2, 1, 0, False),      # c7
+    (2, 256, 8, 8, 128, 3, 2, 1, 1, False),       # c6
+    (1, 6, 5, 7, 4, 3, 2, 1, 1, True),            # ragged
+    (2, 16, 6, 6, 8, 3, 1, 1, 0, True),           # stride 1
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_fwd_bwd(fa, case):
+    N, C, H, W, M, k, s, p, op, bias = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, M, k, k, generator=g) * 0.05
+    b = torch.randn(M, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = F.conv_transpose2d(xr, wr, br, stride=s, padding=p, output_padding=op)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd, wd = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    bd = dev(b).requires_grad_(True) if bias else None
+    out = fa.ops.conv_transpose2d(xd, wd, bd, s, p, op)
+    assert out.shape == ref.shape
+    close(out, ref, rtol=2e-4, atol=2e-5)
+    out.backward(dev(cot))
+    assert rel_l2(xd.grad, xr.grad) < 2e-5
+    assert rel_l2(wd.grad, wr.grad) < 2e-5
+    if bias:
+        close(bd.grad, br.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_conv_error_behaviour(fa):
+    # the reference discriminators fail below 192 px with torch's "Kernel size can't be greater..." 
+    x = torch.zeros(1, 512, 1, 1).cuda()
+    w = torch.zeros(1, 512, 4, 4).cuda()
+    with pytest.raises(RuntimeError, match="Kernel size can't be greater"):
+        fa.ops.conv2d(x, w, None, 1, 1)
+    with pytest.raises(fa.KernelError):
+        fa.ops.conv2d(torch.zeros(1, 3, 8, 8).cuda(), torch.zeros(4, 2, 3, 3).cuda())
+    with pytest.raises(fa.KernelError):
+        fa.ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))       # host tensors must not silently fall back
+
+
+@pytest.mark.parametrize("shape,act,res", [((2, 64, 24, 24), "relu", False), ((4, 128, 6, 6), "lrelu", False),
+                                           ((2, 64, 16, 16), None, True), ((2, 32, 10, 10), "relu", True),
+                                           ((1, 512, 2, 2), "lrelu", False), ((3, 7, 5, 3), None, False)])
+def test_batchnorm_train(fa, shape, act, res):
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=g) * 2 + 0.7
+    gamma = torch.randn(C, generator=g) * 0.1 + 1
+    beta = torch.randn(C, generator=g) * 0.1
+    r = torch.randn(shape, generator=g) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    ref = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    if res:
+        ref = ref + rr
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    cot = torch.randn(shape, generator=g)
+    ref.backward(cot)
+    xd, gd, bd = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    rd = dev(r).requires_grad_(True) if res else None
+    rmd, rvd = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    out = fa.ops.batchnorm_train(xd, gd, bd, rmd, rvd, 0.1, 1e-5, act, 0.2, rd)
+    close(out, ref, rtol=1e-4, atol=2e-5)
+    close(rmd, rm, rtol=1e-5, atol=1e-6)
+    close(rvd, rv, rtol=1e-4, atol=1e-6)
+    out.backward(dev(cot))
+    close(xd.grad, xr.grad, rtol=2e-3, atol=2e-4)
+    assert rel_l2(xd.grad, xr.grad) < 1e-4
+    close(gd.grad, gr.grad, rtol=1e-3, atol=1e-3)
+    close(bd.grad, br.grad, rtol=1e-3, atol=1e-3)
+    if res:
+        close(rd.grad, rr.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_batchnorm_single_value_raises(fa):
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        fa.ops.batchnorm_train(torch.zeros(1, 4, 1, 1).cuda(), torch.ones(4).cuda(), torch.zeros(4).cuda())
+
+
+def test_instancenorm(fa):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 6, 12, 8, generator=g)
+    gamma, beta = torch.randn(6, generator=g), torch.randn(6, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.relu(F.instance_norm(xr, weight=gr, bias=br, eps=1e-5))
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd, gd, bd = dev(x).requires_grad_(True), dev(gamma).requires_grad_(True), dev(beta).requires_grad_(True)
+    out = fa.ops.instance_norm(xd, gd, bd, 1e-5, "relu")
+    close(out, ref, rtol=1e-4, atol=2e-5)
+    out.backward(dev(cot))
+    close(xd.grad, xr.grad, rtol=2e-3, atol=2e-4)
+    close(gd.grad, gr.grad, rtol=1e-3, atol=1e-3)
+    close(bd.grad, br.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_pointwise(fa):
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(2, 5, 7, 9, generator=g), torch.randn(2, 3, 7, 9, generator=g)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.relu(torch.cat([ar, br], 1))
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    ad, bd = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    out = fa.ops.cat2_act(ad, bd, "relu")
+    close(out, ref, rtol=0, atol=0)
+    out.backward(dev(cot))
+    close(ad.grad, ar.grad, rtol=0, atol=0)
+    close(bd.grad, br.grad, rtol=0, atol=0)
+    for act, fn in (("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.2)), ("tanh", torch.tanh)):
+        xr = a.clone().requires_grad_(True)
+        r = fn(xr)
+        r.backward(torch.ones_like(r))
+        xd = dev(a).requires_grad_(True)
+        o = fa.ops.activation(xd, act, 0.2)
+        close(o, r, rtol=1e-6, atol=1e-6)
+        o.backward(torch.ones_like(o))
+        close(xd.grad, xr.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_haar_dwt_vs_golden_and_oracle(fa, O):
+    ops_g = np.load(os.path.join(GOLD, "golden_ops.npz"))
+    x8 = torch.arange(64, dtype=torch.float32).reshape(1, 1, 8, 8)
+    f1 = fa.DWTForward(J=1, wave="haar", mode="reflect").cuda()
+    yl, yh = f1(dev(x8))
+    assert yl.is_contiguous() and yh[0].is_contiguous()          # pytorch_wavelets/tests/test_dwt.py:47-50
+    close(yl, ops_g["dwt8_ll"], atol=1e-5)
+    close(yh[0], ops_g["dwt8_hi"], atol=1e-5)
+    gen = torch.Generator().manual_seed(11)
+    x16 = torch.randn(2, 3, 16, 16, generator=gen)
+    xd = dev(x16).requires_grad_(True)
+    f3 = fa.DWTForward(J=3, wave="haar", mode="reflect").cuda()
+    yl, yh = f3(xd)
+    close(yl, ops_g["dwt16_ll"], atol=2e-6)
+    for j in range(3):
+        close(yh[j], ops_g["dwt16_hi%d" % j], atol=2e-6)
+    cot = [torch.randn(t.shape, generator=gen) for t in [yl] + list(yh)]
+    sum((dev(c) * t).sum() for c, t in zip(cot, [yl] + list(yh))).backward()
+    close(xd.grad, ops_g["dwt16_grad"], atol=2e-6)
+    inv = fa.DWTInverse(wave="haar", mode="reflect").cuda()
+    cl = [dev(c).requires_grad_(True) for c in cot]
+    rec = inv((cl[0], cl[1:]))
+    close(rec, ops_g["idwt16_out"], atol=2e-6)
+    cot2 = torch.randn(rec.shape, generator=gen)
+    (rec * dev(cot2)).sum().backward()
+    close(cl[0].grad, ops_g["idwt16_grad_ll"], atol=2e-6)
+    close(cl[1].grad, ops_g["idwt16_grad_hi0"], atol=2e-6)
+    close(inv((dev(cot[0]), [dev(cot[1]), None, dev(cot[3])])), ops_g["idwt16_none_out"], atol=2e-6)
+    # perfect reconstruction at the benchmark size, a size-independent property (test_dwt.py:64-81)
+    xb = torch.randn(8, 1, 256, 256).cuda()
+    f3b = fa.DWTForward(J=3, wave="haar", mode="reflect").cuda()
+    yl, yh = f3b(xb)
+    assert yl.shape == (8, 1, 32, 32) and yh[0].shape == (8, 1, 3, 128, 128)
+    close(inv((yl, yh)), xb, atol=2e-6, rtol=0)
+    # fused discriminator front ends
+    xs = torch.rand(3, 1, 32, 48) * 2 - 1
+    ll, yh = O.haar_dwt2(xs, 1)
+    close(fa.ops.haar_dfront(dev(xs), 0), ll, atol=1e-6)
+    cat = torch.cat([yh[0][:, :, 0], yh[0][:, :, 1], yh[0][:, :, 2]], 1) * 0.5 + 0.5
+    close(fa.ops.haar_dfront(dev(xs), 1), cat, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        fa.DWTForward(J=1, wave="db3")
+    with pytest.raises(NotImplementedError):
+        f1(torch.zeros(1, 1, 7, 8).cuda())
+
+
+def test_freq_split_vs_golden_and_oracle(fa, O):
+    ops_g = np.load(os.path.join(GOLD, "golden_ops.npz"))
+    gen = torch.Generator().manual_seed(11)
+    torch.randn(2, 3, 16, 16, generator=gen)
+    for s in [(2, 3, 2, 2), (2, 3, 3, 8, 8), (2, 3, 3, 4, 4), (2, 3, 3, 2, 2), (2, 3, 16, 16)]:
+        torch.randn(s, generator=gen)
+    x64 = torch.rand(2, 1, 64, 64, generator=gen) * 2 - 1
+    for r in (5, 8, 10, 14):
+        hp = torch.stack([fa.high_pass(dev(x64[b]), r) for b in range(2)])
+        lp = torch.stack([fa.low_pass(dev(x64[b]), r) for b in range(2)])
+        close(hp, ops_g["hp64_r%d" % r], rtol=1e-4, atol=3e-6)
+        close(lp, ops_g["lp64_r%d" % r], rtol=1e-4, atol=3e-6)
+    w = torch.randn(64, 64, generator=gen)
+    xg = dev(x64[0]).requires_grad_(True)
+    (fa.high_pass(xg, 10) * dev(w)).sum().backward()
+    close(xg.grad, ops_g["hp64_r10_grad"], rtol=1e-3, atol=2e-5)
+    xg = dev(x64[0]).requires_grad_(True)
+    (fa.low_pass(xg, 8) * dev(w)).sum().backward()
+    close(xg.grad, ops_g["lp64_r8_grad"], rtol=1e-3, atol=2e-5)
+    x192 = torch.rand(1, 192, 192, generator=gen) * 2 - 1
+    for r in (5, 14):
+        close(fa.high_pass(dev(x192), r)[:16, :16], ops_g["hp192_r%d_crop" % r], rtol=1e-4, atol=5e-6)
+        close(fa.low_pass(dev(x192), r)[-16:, -16:], ops_g["lp192_r%d_crop" % r], rtol=1e-4, atol=5e-6)
+    x33 = torch.rand(1, 30, 34, generator=gen) * 2 - 1
+    close(fa.high_pass(dev(x33)), ops_g["hp30x34_r4"], rtol=1e-4, atol=3e-6)
+    close(fa.low_pass(dev(x33)), ops_g["lp30x34_r10"], rtol=1e-4, atol=3e-6)
+    # batched split with gradients at the benchmark size vs the oracle's FFT form
+    xb = torch.rand(3, 1, 256, 256) * 2 - 1
+    xr = xb.clone().requires_grad_(True)
+    hf_r, lf_r = O.freq_split(xr, 10, 8)
+    c1, c2 = torch.randn(hf_r.shape), torch.randn(lf_r.shape)
+    ((hf_r * c1).sum() + (lf_r * c2).sum()).backward()
+    xd = dev(xb).requires_grad_(True)
+    hf, lf = fa.frequency_split(xd, 10, 8)
+    close(hf, hf_r, rtol=1e-4, atol=5e-6)
+    close(lf, lf_r, rtol=1e-4, atol=5e-6)
+    ((hf * dev(c1)).sum() + (lf * dev(c2)).sum()).backward()
+    assert rel_l2(xd.grad, xr.grad) < 1e-5
+
+
+def test_ssim_vs_golden_and_oracle(fa, O):
+    ops_g = np.load(os.path.join(GOLD, "golden_ops.npz"))
+    gen = torch.Generator().manual_seed(11)
+    torch.randn(2, 3, 16, 16, generator=gen)
+    for s in [(2, 3, 2, 2), (2, 3, 3, 8, 8), (2, 3, 3, 4, 4), (2, 3, 3, 2, 2), (2, 3, 16, 16)]:
+        torch.randn(s, generator=gen)
+    torch.rand(2, 1, 64, 64, generator=gen); torch.randn(64, 64, generator=gen)
+    torch.rand(1, 192, 192, generator=gen); torch.rand(1, 30, 34, generator=gen)
+    a = torch.rand(2, 1, 32, 32, generator=gen) * 2 - 1
+    b = (a + 0.3 * torch.randn(2, 1, 32, 32, generator=gen)).clamp(-1, 1)
+    ad, bd = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    v = fa.SSIM()(ad, bd)
+    v.backward()
+    assert float(v) == pytest.approx(float(ops_g["ssim32_mean"]), rel=1e-5)
+    close(ad.grad, ops_g["ssim32_grad1"], rtol=1e-3, atol=1e-6)
+    close(bd.grad, ops_g["ssim32_grad2"], rtol=1e-3, atol=1e-6)
+    close(fa.ssim(dev(a), dev(b), size_average=False), ops_g["ssim32_per_sample"], rtol=1e-5, atol=1e-6)
+    a3 = torch.rand(1, 3, 24, 40, generator=gen)
+    b3 = torch.rand(1, 3, 24, 40, generator=gen)
+    assert float(fa.ssim(dev(a3), dev(b3))) == pytest.approx(float(ops_g["ssim_c3"]), rel=1e-5)
+    # benchmark-size check against the oracle, including the per-sample gradient path
+    ab = torch.rand(4, 1, 256, 256) * 2 - 1
+    bb = (ab + 0.2 * torch.randn_like(ab)).clamp(-1, 1)
+    ar = ab.clone().requires_grad_(True)
+    vr = O.ssim(ar, bb, size_average=False)
+    wt = torch.tensor([1.0, -2.0, 0.5, 3.0])
+    (vr * wt).sum().backward()
+    ad = dev(ab).requires_grad_(True)
+    vd = fa.ssim(ad, dev(bb), size_average=False)
+    close(vd, vr, rtol=1e-5, atol=1e-6)
+    (vd * dev(wt)).sum().backward()
+    assert rel_l2(ad.grad, ar.grad) < 1e-4
+    assert float(fa.ssim(dev(ab), dev(ab))) == pytest.approx(1.0, abs=1e-6)     # identity property
+
+
+def test_losses_head_adamw(fa, O):
+    ops_g = np.load(os.path.join(GOLD, "golden_ops.npz"))
+    g = torch.Generator().manual_seed(21)
+    a, b = torch.randn(2, 4, 6, 6, generator=g), torch.randn(2, 4, 6, 6, generator=g)
+    for name, fn, ref in (("mse", fa.ops.mse_loss, F.mse_loss), ("l1", fa.ops.l1_loss, F.l1_loss),
+                          ("bce", fa.ops.bce_with_logits, F.binary_cross_entropy_with_logits)):
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        r = ref(ar, br) * 1.7
+        r.backward()
+        ad, bd = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+        o = fn(ad, bd, 1.7)
+        assert float(o) == pytest.approx(float(r), rel=1e-5), name
+        o.backward()
+        close(ad.grad, ar.grad, rtol=1e-4, atol=1e-7)
+        close(bd.grad, br.grad, rtol=1e-4, atol=1e-7)
+    # the reference's BCE target-gradient fixture (train.py:230-231)
+    gen = torch.Generator().manual_seed(11)
+    # (value and grad are regenerated from the oracle-side statement: grad wrt target = -x/N)
+    xi, tt = torch.randn(2, 4, 6, 6), torch.randn(2, 4, 6, 6)
+    td = dev(tt).requires_grad_(True)
+    fa.ops.bce_with_logits(dev(xi), td).backward()
+    close(td.grad, -xi / xi.numel(), rtol=1e-5, atol=1e-8)
+    assert ops_g["bce_tgrad"].shape == (2, 4, 6, 6)
+    # discriminator head
+    p, q = torch.randn(3, 1, 6, 6, generator=g), torch.randn(3, 1, 2, 2, generator=g)
+    pr, qr = p.clone().requires_grad_(True), q.clone().requires_grad_(True)
+    r = torch.flatten(0.7 * pr.mean(dim=(2, 3)).view(3, -1) + 0.3 * qr.mean(dim=(2, 3)).view(3, -1))
+    cot = torch.randn(3, generator=g)
+    r.backward(cot)
+    pd, qd = dev(p).requires_grad_(True), dev(q).requires_grad_(True)
+    o = fa.ops.mean_mix(pd, qd)
+    close(o, r, rtol=1e-5, atol=1e-6)
+    o.backward(dev(cot))
+    close(pd.grad, pr.grad, rtol=1e-5, atol=1e-8)
+    close(qd.grad, qr.grad, rtol=1e-5, atol=1e-8)
+    # AdamW: 3 steps against the oracle's restatement of torch.optim.AdamW
+    w0 = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=g) for _ in range(3)]
+    pr = w0.clone().requires_grad_(True)
+    opt = O.AdamW([pr])
+    lin = torch.nn.Linear(10, 100, bias=False).cuda()
+    lin.weight.data.copy_(w0.view(100, 10))
+    arena = fa.ParamArena([("weight", lin.weight)], lr=1.3e-4)
+    for gr in grads:
+        pr.grad = gr.clone()
+        opt.step()
+        arena.grad.copy_(gr)
+        arena.step()
+    close(lin.weight.view(-1), pr, rtol=1e-6, atol=1e-7)
+    assert lin.weight.data_ptr() == arena.flat.data_ptr()
