@@ -15,6 +15,15 @@ TIGHT = ("loss_G", "loss_cycle_ABA", "loss_cycle_BAB", "loss_idt")
 LOOSE = ("loss_GAN_A2B", "loss_GAN_B2A", "loss_D_A", "loss_D_B")
 
 
+def host_threads():
+    """CPU threads this process may really use (the GPU box grants ~16 of the host's cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 @pytest.fixture(scope="module")
 def fa():
     import faoctasr
@@ -117,7 +126,7 @@ def test_train_step_batched_vs_oracle(fa, O):
     n = build_nets(fa, O)
     ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"])
     S = O.StepOracle(seed=0)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(host_threads())
     for step in range(2):
         a, b = O.synthetic_batch(2, 192, seed=1234 + 17 * step)
         L = ts.step(a.cuda(), b.cuda(), sync=True)
