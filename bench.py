@@ -1,0 +1,206 @@
+"""Benchmark of the north-star path: one full G+D train step (train.py:166-269 semantics) on synthetic
+256x256 single-channel OCTA batches.
+
+  python bench.py --gpus N --steps K --warmup W
+N=1: BASELINE.json configs[1] (256x256x1, batch 8, fp32, 1 MI355X).  N>1 (launched by the driver through
+torch.distributed.run, one rank per GPU): the same per-GPU batch on every rank (weak scaling), gradients of the two
+flat arenas all-reduced over RCCL per optimizer phase.  Rank 0 prints ONE JSON line.
+
+Beside the headline value the line carries
+  roofline:     the dominant kernel (the implicit-GEMM gather kernel = conv forward + input-gradient) timed with HIP
+                events on the launch stream over extra steps of the same workload: algorithmic FLOP / measured time
+                against the f32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline: the CPU oracle (oracle/octa_oracle.py, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+GATHER = ("conv2d_fwd", "conv2d_dgrad", "conv_transpose2d_fwd", "conv_transpose2d_dgrad")
+WGRAD = ("conv2d_wgrad", "conv_transpose2d_wgrad")
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def conv_flops(name, a):
+    """Algorithmic FLOPs (2*MACs) of one convolution-family launch from its C-ABI arguments."""
+    if name in ("conv2d_fwd", "conv_transpose2d_fwd"):
+        N, C, IH, IW, M, KH, KW, stride, pad = a[4:13]
+    else:
+        N, C, IH, IW, M, KH, KW, stride, pad = a[3:12]
+    if name.startswith("conv2d"):
+        OH, OW = (IH + 2 * pad - KH) // stride + 1, (IW + 2 * pad - KW) // stride + 1
+        return 2.0 * N * M * OH * OW * C * KH * KW
+    return 2.0 * N * C * IH * IW * M * KH * KW          # transposed: every input pixel meets every tap
+
+
+class LaunchTimer:
+    def __init__(self, names):
+        self.names = set(names)
+        self.rec = []
+
+    def add(self, name, args, s, e):
+        self.rec.append((name, conv_flops(name, args), s, e))
+
+    def summary(self, group):
+        ms = sum(s.elapsed_time(e) for n, f, s, e in self.rec if n in group)
+        fl = sum(f for n, f, s, e in self.rec if n in group)
+        cnt = sum(1 for n, f, s, e in self.rec if n in group)
+        return ms, fl, cnt
+
+
+def make_batch(B, H, device, rank):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    a = (torch.rand(B, 1, H, H, generator=g) * 2 - 1).to(device)
+    b = (torch.rand(B, 1, H, H, generator=g) * 2 - 1).to(device)
+    return a, b
+
+
+def cpu_baseline(H, budget_s=30.0):
+    """The CPU oracle on the host cores, bounded: one step at batch 2 (per-image work identical to the workload)."""
+    from oracle import octa_oracle as O
+    nt = host_threads()
+    torch.set_num_threads(nt)
+    S = O.StepOracle(seed=0)
+    B = 2
+    a, b = O.synthetic_batch(B, H)
+    t0 = time.time()
+    S.train_step(a, b)
+    dt = time.time() - t0
+    steps = 1
+    if dt < budget_s / 3:
+        t0 = time.time()
+        S.train_step(a, b)
+        dt = time.time() - t0
+        steps = 2
+    return {"value": round(B / dt, 4), "unit": "images/s", "cores": nt, "kind": "port",
+            "sample": "CPU oracle, %d step(s) run, last timed: %dx%d batch %d fp32 train step, %d torch threads (%.1f s)" % (steps, H, H, B, nt, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config 2: 8)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        print("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import faoctasr
+    from faoctasr import _lib
+    _lib.load()                                  # fails loudly when the HIP library is missing
+    torch.manual_seed(0)
+    import random
+    random.seed(1234 + rank)
+    ts = faoctasr.TrainStep(device=device, distributed=distributed)
+    if distributed:                              # identical replicas: broadcast rank 0's arenas and buffers
+        for t in (ts.opt_G.flat, ts.opt_D.flat):
+            dist.broadcast(t, 0)
+    B, H = args.batch, args.size
+    real_A, real_B = make_batch(B, H, device, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(real_A, real_B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        L = ts.step(real_A, real_B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_G = float(L["loss_G"])
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    roof = None
+    extra = {}
+    if rank == 0 and not args.no_roofline:
+        timer = LaunchTimer(GATHER + WGRAD)
+        _lib.launch_timer = timer
+        nroof = max(1, min(3, args.steps))
+        for _ in range(nroof):
+            ts.step(real_A, real_B)
+        torch.cuda.synchronize()
+        _lib.launch_timer = None
+        ms, fl, cnt = timer.summary(GATHER)
+        ach = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("igemm_gather_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": "igemm_gather_kernel (conv fwd + dgrad, f32 MFMA 32x32x2)", "achieved": round(ach, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "launches_per_step": cnt // nroof, "avg_launch_us": round(1e3 * ms / cnt, 2),
+                "gflop_per_launch": round(fl / cnt / 1e9, 3)}
+        ms2, fl2, cnt2 = timer.summary(WGRAD)
+        extra["roofline_wgrad"] = {"bound": "mfma", "kernel": "igemm_wgrad_kernel", "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
+                                   "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                   "launches_per_step": cnt2 // nroof, "avg_launch_us": round(1e3 * ms2 / cnt2, 2)}
+        extra["conv_ms_per_step"] = round((ms + ms2) / nroof, 2)
+        extra["conv_tflop_per_step"] = round((fl + fl2) / nroof / 1e12, 3)
+    if distributed:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(H)
+        line = {"metric": "train-step images/sec (G+D fwd+bwd) on 256x256 OCTA", "value": round(value, 3), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%dx%dx1 OCTA pairs, batch %d per GPU, fp32, full G+D train step "
+                                       "(4 frequency splits, 6 G fwd, 6 D fwd, 3 backward, 2 AdamW)" % (H, H, B),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss_G": round(loss_G, 5)},
+                "roofline": roof, "cpu_baseline": cpu}
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,9 +95,21 @@ def ptr(t):
     return t.data_ptr()
 
 
+#: optional launch timer (bench.py installs one): an object with ``names`` and ``add(name, args, start_event, end_event)``
+launch_timer = None
+
+
 def call(name, *args):
     lib = _lib or load()
-    rc = getattr(lib, "faoctasr_" + name)(*args)
+    t = launch_timer
+    if t is not None and name in t.names:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, "faoctasr_" + name)(*args)
+        e.record()
+        t.add(name, args, s, e)
+    else:
+        rc = getattr(lib, "faoctasr_" + name)(*args)
     if rc != 0:
         raise KernelError("faoctasr_%s failed (%d): %s" % (name, rc, lib.faoctasr_last_error().decode()))
 
