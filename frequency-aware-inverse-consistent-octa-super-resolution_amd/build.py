@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["igemm.hip", "pointwise.hip", "sgemm.hip", "ssim.hip"]
+SOURCES = ["igemm.hip", "igemm_patch.hip", "pointwise.hip", "sgemm.hip", "ssim.hip"]
 LIB = os.path.join(HERE, "libfaoctasr.so")
 
 
@@ -12,7 +12,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "common.h"), os.path.join(ROOT, "include", "faoctasr.h")]
+    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(ROOT, "include", "faoctasr.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -14,23 +14,11 @@
 // 458 (3x3 s2), 494,499 (3x3 @256ch); backward = aten::convolution_backward under
 // loss.backward() (train.py:238,255,267).
 #include "common.h"
+#include "igemm_geom.h"
 
 namespace faoctasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct IgemmGeom {
-    int N, C, IH, IW;      // gather source tensor
-    int M, OH, OW;         // output tensor
-    int SI, SO;            // input step / output step per sub-grid step
-    int nphase;
-    int reflect;
-    int act;
-    float slope;
-    long wsm, wsc;         // weight strides (elements) for output channel m / gathered channel c
-    int ph_py[4], ph_px[4], ph_gh[4], ph_gw[4], ph_t0[5];
-    int taps[64];          // packed (oy+64) | (ox+64)<<8 | widx<<16
-};
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -44,7 +32,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 template <int MT>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
-                                                           const IgemmGeom g) {
+                                                           const IgemmGeom g, const int ksplit) {
     constexpr int NT = 128, KC = 16, LDA = KC + 1;
     constexpr int MI = MT / 64;          // 32-row MFMA tiles per wave along M
     constexpr int NA = MT * KC / 256;    // A elements staged per thread
@@ -53,14 +41,21 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restri
     __shared__ int taps_s[64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ph = blockIdx.z;
+    const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.ph_gh[ph], GW = g.ph_gw[ph];
     const int t0 = g.ph_t0[ph], T = g.ph_t0[ph + 1] - t0;
     const long npix = (long)g.N * GH * GW;
     const long j0 = (long)blockIdx.x * NT;
     if (j0 >= npix) return;
     const int m0 = blockIdx.y * MT;
-    const int K = g.C * T;
+    const int Kfull = g.C * T;
+    // split-K: this block reduces chunks [kbeg, K) of the phase's K range and adds its partial tile atomically
+    const int nchunks_all = (Kfull + KC - 1) / KC;
+    const int cps = (nchunks_all + ksplit - 1) / ksplit;
+    const int kbeg = ks * cps * KC;
+    int K = (ks + 1) * cps * KC;
+    K = K < Kfull ? K : Kfull;
+    if (ksplit > 1 && kbeg >= K) return;
     const float invT = T > 0 ? 1.0f / (float)T : 0.f;
     const int IH = g.IH, IW = g.IW;
     const long chw = (long)IH * IW;
@@ -128,8 +123,8 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restri
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    load_chunk(0);
-    for (int k0 = 0; k0 < K || k0 == 0; k0 += KC) {
+    load_chunk(kbeg);
+    for (int k0 = kbeg; k0 < K || k0 == kbeg; k0 += KC) {
         __syncthreads();   // previous chunk's MFMA reads are done
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -153,7 +148,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restri
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (K == 0) break;
+        if (K <= kbeg) break;
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -174,8 +169,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restri
                 const int m = m0 + wm * (MT / 2) + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
                 if (m < g.M) {
                     float v = acc[mi][ni][rr];
-                    if (bias) v += bias[m];
-                    y[obase + (long)m * ohw] = act_apply(v, g.act, g.slope);
+                    if (bias && ks == 0) v += bias[m];
+                    if (ksplit > 1) atomicAdd(y + obase + (long)m * ohw, v);
+                    else y[obase + (long)m * ohw] = act_apply(v, g.act, g.slope);
                 }
             }
         }
@@ -361,10 +357,26 @@ static int launch_gather(const float* x, const float* w, const float* bias, floa
     const long blocks128 = gx * ((g.M + 127) / 128) * g.nphase;
     if (g.M >= 128 && blocks128 >= 512) {
         dim3 grid((unsigned)gx, (g.M + 127) / 128, g.nphase);
-        hipLaunchKernelGGL(igemm_gather_kernel<128>, grid, dim3(256), 0, s, x, w, bias, y, g);
+        hipLaunchKernelGGL(igemm_gather_kernel<128>, grid, dim3(256), 0, s, x, w, bias, y, g, 1);
     } else {
-        dim3 grid((unsigned)gx, (g.M + 63) / 64, g.nphase);
-        hipLaunchKernelGGL(igemm_gather_kernel<64>, grid, dim3(256), 0, s, x, w, bias, y, g);
+        // few pixels and a long reduction (the deep discriminator layers: 8x8 maps, K = 8192): split K over
+        // blockIdx.z and accumulate with fp32 atomics into a zeroed output (no fused activation in that mode)
+        const long blocks64 = gx * ((g.M + 63) / 64) * g.nphase;
+        int maxT = 0;
+        for (int p = 0; p < g.nphase; ++p) maxT = g.ph_t0[p + 1] - g.ph_t0[p] > maxT ? g.ph_t0[p + 1] - g.ph_t0[p] : maxT;
+        const int nchunks = (g.C * maxT + 15) / 16;
+        int ksplit = 1;
+        if (act == FAOCTASR_ACT_NONE && blocks64 < 384 && nchunks >= 8) {
+            ksplit = (int)((768 + blocks64 - 1) / blocks64);
+            if (ksplit > nchunks / 4) ksplit = nchunks / 4;
+            if (ksplit < 1) ksplit = 1;
+        }
+        if (ksplit > 1) {
+            hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s);
+            if (e != hipSuccess) return fail(FAOCTASR_EHIP, "memset y: %s", hipGetErrorString(e));
+        }
+        dim3 grid((unsigned)gx, (g.M + 63) / 64, g.nphase * ksplit);
+        hipLaunchKernelGGL(igemm_gather_kernel<64>, grid, dim3(256), 0, s, x, w, bias, y, g, ksplit);
     }
     return check_launch("igemm_gather");
 }
@@ -392,14 +404,55 @@ static int launch_wgrad(const float* x, const float* dy, float* dw, IgemmGeom& g
 
 static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || !b || !c; }
 
+// wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
+static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
+                      int wpack_state, hipStream_t s) {
+    if (wpack && wpack_state) {
+        PatchGeom pg;
+        int rc = patch_geom_from(g, pg);
+        if (rc) return rc;
+        if (wpack_state == 1) {
+            rc = launch_pack(w, wpack, pg, s);
+            if (rc) return rc;
+        }
+        rc = launch_patch(x, wpack, bias, y, pg, act, slope, s);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+    }
+    return launch_gather(x, w, bias, y, g, act, slope, s);
+}
+
+static long wpack_floats(IgemmGeom& g) {
+    PatchGeom pg;
+    if (patch_geom_from(g, pg)) return 0;
+    return patch_pack_floats(pg);
+}
+
 }  // namespace faoctasr
 
 using namespace faoctasr;
 
 extern "C" {
 
+// kind: 0 conv2d fwd, 1 conv2d dgrad, 2 conv_transpose2d fwd, 3 conv_transpose2d dgrad.  (C, M) as in the matching call.
+long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad) {
+    IgemmGeom g;
+    const long kk = (long)KH * KW;
+    // spatial sizes do not enter the packed layout; use a nominal 64x64 grid
+    int rc;
+    switch (kind) {
+        case 0: rc = geom_fwd(g, 1, C, 64, 64, M, 64, 64, KH, KW, stride, pad, 0, (long)C * kk, kk); break;
+        case 1: rc = geom_transposed(g, 1, M, 64, 64, C, 64, 64, KH, KW, stride, pad, kk, (long)C * kk); break;
+        case 2: rc = geom_transposed(g, 1, C, 64, 64, M, 64, 64, KH, KW, stride, pad, kk, (long)M * kk); break;
+        case 3: rc = geom_fwd(g, 1, M, 64, 64, C, 64, 64, KH, KW, stride, pad, 0, (long)M * kk, kk); break;
+        default: return fail(FAOCTASR_EINVAL, "conv_wpack_floats: unknown kind %d", kind);
+    }
+    if (rc) return rc;
+    return wpack_floats(g);
+}
+
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,
-                        int KH, int KW, int stride, int pad, int reflect, int act, float slope, faoctasr_stream_t stream) {
+                        int KH, int KW, int stride, int pad, int reflect, int act, float slope, float* wpack, int wpack_state,
+                        faoctasr_stream_t stream) {
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv2d_fwd: null pointer");
     if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
@@ -407,11 +460,11 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return launch_gather(x, w, bias, y, g, act, slope, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, (hipStream_t)stream);
 }
 
 int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW,
-                          int stride, int pad, faoctasr_stream_t stream) {
+                          int stride, int pad, float* wpack, int wpack_state, faoctasr_stream_t stream) {
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
@@ -419,7 +472,7 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
     // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
     int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
     if (rc) return rc;
-    return launch_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, (hipStream_t)stream);
 }
 
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
@@ -434,8 +487,8 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
 }
 
 int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW,
-                                  int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope,
-                                  faoctasr_stream_t stream) {
+                                  int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope, float* wpack,
+                                  int wpack_state, faoctasr_stream_t stream) {
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: bad shape");
@@ -443,18 +496,19 @@ int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* b
     // w[c][m][t]: m stride = KK, c stride = M*KK
     int rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, (long)KH * KW, (long)M * KH * KW);
     if (rc) return rc;
-    return launch_gather(x, w, bias, y, g, act, slope, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, (hipStream_t)stream);
 }
 
 int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH,
-                                    int KW, int stride, int pad, int out_pad, faoctasr_stream_t stream) {
+                                    int KW, int stride, int pad, int out_pad, float* wpack, int wpack_state,
+                                    faoctasr_stream_t stream) {
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_dgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;
     // dx[n][c][iy][ix] = sum_{m,t} dy[n][m][iy*s-p+kh][..] * w[c][m][t]: forward-mode gather over dy
     int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return launch_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, (hipStream_t)stream);
 }
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,

@@ -1,0 +1,39 @@
+// Geometry descriptors shared by the flat (igemm.hip) and LDS-patch (igemm_patch.hip) implicit-GEMM kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace faoctasr {
+
+constexpr int PATCH_MAX_PER_THREAD = 20;   // patch elements staged per thread (256 threads)
+
+// flat im2col kernel: taps packed (oy+64) | (ox+64)<<8 | widx<<16
+struct IgemmGeom {
+    int N, C, IH, IW;      // gather source tensor
+    int M, OH, OW;         // output tensor
+    int SI, SO;            // input step / output step per sub-grid step
+    int nphase;
+    int reflect;
+    int act;
+    float slope;
+    long wsm, wsc;         // weight strides (elements) for output channel m / gathered channel c
+    int ph_py[4], ph_px[4], ph_gh[4], ph_gw[4], ph_t0[5];
+    int taps[64];
+};
+
+// LDS-patch kernel: taps packed relative to the patch origin, (oy-oy0) | (ox-ox0)<<8 | widx<<16
+struct PatchGeom {
+    int N, C, IH, IW, M, OH, OW, SI, SO, nphase, reflect, act;
+    float slope;
+    int Mpad;
+    long wsm, wsc;
+    int py[4], px[4], gh[4], gw[4], t0[5], kc[4], oy0[4], ox0[4], span_y[4], span_x[4];
+    long pack_off[5];
+    int taps[64];
+};
+
+int patch_geom_from(const IgemmGeom& f, PatchGeom& g);
+long patch_pack_floats(const PatchGeom& g);
+int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s);
+int launch_patch(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s);
+
+}  // namespace faoctasr

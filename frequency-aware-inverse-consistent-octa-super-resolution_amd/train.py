@@ -70,6 +70,7 @@ class ParamArena:
         self.step_count += 1
         call("adamw_step", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, self.lr, self.betas[0],
              self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream_ptr())
+        ops.invalidate_weight_cache()      # the kernel changed the weights through raw pointers: packed images are stale
 
 
 class TrainStep:
