@@ -78,11 +78,11 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 template <int WM, int WN, int MI, int NI, int SI>
 __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
-                                                          const PatchGeom g) {
+                                                          const PatchGeom g, const int ksplit) {
     constexpr int MT = WM * MI * 32, TH = WN * NI, NPV = PATCH_MAX_PER_THREAD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ph = blockIdx.z;
+    const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
     const int tiles_x = (GW + 31) >> 5, tiles_y = (GH + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y;
@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
     const int IH = g.IH, IW = g.IW;
     const long chw = (long)IH * IW;
     const int nchunks = (g.C + KC - 1) / KC;
+    // split-K: this block reduces chunks [ch0, ch1) and adds its partial tile atomically (output zeroed by the launcher)
+    const int cps = (nchunks + ksplit - 1) / ksplit;
+    const int ch0 = ks * cps;
+    const int ch1 = (ch0 + cps) < nchunks ? (ch0 + cps) : nchunks;
+    if (ch0 >= ch1) return;
     const int y_base = ty * TH * SI + g.oy0[ph], x_base = tx * 32 * SI + g.ox0[ph];
     const float* xin = x + (long)n * g.C * chw;
     const float* wslab = wp + g.pack_off[ph] + m0;                 // + (chunk*KC*T + r)*Mpad
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
     const int a_lane = lh * MT + wm * (MI * 32) + l31;
     const int b_lane = lh * PHW + (wn * NI) * SI * PW + l31 * SI;
 
-    issue_A(0, 0);
-    load_patch(0);
-    store_patch(0, 0);
+    issue_A(ch0, 0);
+    load_patch(ch0);
+    store_patch(0, ch0);
     __syncthreads();
 
     const int nsteps = T * (KC >> 1);                  // MFMA k-steps per chunk: (tap, channel pair)
@@ -195,9 +200,9 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
         const int tp = g.taps[t0 + lane];
         tapv = (tp & 0xff) * PW + ((tp >> 8) & 0xff);
     }
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nchunks) {
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int cur = (ch - ch0) & 1;
+        if (ch + 1 < ch1) {
             issue_A(ch + 1, cur ^ 1);
             load_patch(ch + 1);
         }
@@ -251,13 +256,13 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (ch + 1 < nchunks) store_patch(cur ^ 1, ch + 1);
+        if (ch + 1 < ch1) store_patch(cur ^ 1, ch + 1);
         __syncthreads();      // LDS-DMA of the next A slab has landed (vmcnt(0)), next patch visible, this chunk's reads done
     }
 
     // epilogue: bias and activation on the accumulator registers (activation switch hoisted out of the store loops)
     const int mrow0 = m0 + wm * (MI * 32) + 4 * lh;
-    if (bias) {
+    if (bias && ks == 0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -303,7 +308,10 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
-                if (m < g.M) yo[(long)m * ohw] = acc[mi][ni][rr];
+                if (m < g.M) {
+                    if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
+                    else yo[(long)m * ohw] = acc[mi][ni][rr];
+                }
             }
         }
     }
@@ -420,7 +428,7 @@ static long patch_blocks(const PatchGeom& g) {
 }
 
 template <int WM, int WN, int MI, int NI>
-static int launch_cfg(const float* x, const float* wp, const float* bias, float* y, const PatchGeom& g, hipStream_t s) {
+static int launch_cfg(const float* x, const float* wp, const float* bias, float* y, const PatchGeom& g, int ksplit, hipStream_t s) {
     constexpr int MT = WM * MI * 32, TH = WN * NI;
     long mx = 0;
     for (int p = 0; p < g.nphase; ++p) {
@@ -428,18 +436,35 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
         if (t > mx) mx = t;
     }
     if (mx == 0) return FAOCTASR_OK;
-    dim3 grid((unsigned)mx, (g.M + MT - 1) / MT, g.nphase);
+    if (ksplit > 1) {
+        hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s);
+        if (e != hipSuccess) return fail(FAOCTASR_EHIP, "memset y: %s", hipGetErrorString(e));
+    }
+    dim3 grid((unsigned)mx, (g.M + MT - 1) / MT, g.nphase * ksplit);
     const size_t lds = patch_lds_bytes<WM, WN, MI, NI>(g, g.SI);
     if (g.SI == 1) {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
     } else {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 2>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
     }
     return check_launch("igemm_patch");
+}
+
+// split K when the tile grid alone cannot fill 256 CUs twice over (no fused activation in that mode)
+static int pick_ksplit(const PatchGeom& g, long blocks, int act) {
+    if (act != FAOCTASR_ACT_NONE || blocks >= 384) return 1;
+    int minchunks = 1 << 30;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int nc = (g.C + g.kc[p] - 1) / g.kc[p];
+        minchunks = nc < minchunks ? nc : minchunks;
+    }
+    int ks = (int)((640 + blocks - 1) / blocks);
+    if (ks > minchunks / 2) ks = minchunks / 2;
+    return ks < 1 ? 1 : ks;
 }
 
 // returns 1 when the patch kernel was launched, 0 when the shape is left to the flat kernel, <0 on error
@@ -450,10 +475,15 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
         if (g.gw[p] < 24 || g.t0[p + 1] - g.t0[p] == 0) return 0;       // narrow maps: the flat kernel wastes fewer lanes
     // config A: 128 x (4x32); B: 64 x (8x32); C: 64 x (4x32)
     int rc;
-    if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI) && patch_blocks<2, 2, 2, 2>(g) >= 384) rc = launch_cfg<2, 2, 2, 2>(x, wp, bias, y, g, s);
-    else if (g.M <= 64 && patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 384) rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, s);
-    else if (patch_fits<2, 2, 1, 2>(g, g.SI)) rc = launch_cfg<2, 2, 1, 2>(x, wp, bias, y, g, s);
-    else return 0;
+    if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
+        rc = launch_cfg<2, 2, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 2, 2>(g), act), s);
+    } else if (g.M <= 64 && patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 256) {
+        rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);
+    } else if (patch_fits<2, 2, 1, 2>(g, g.SI)) {
+        rc = launch_cfg<2, 2, 1, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 1, 2>(g), act), s);
+    } else {
+        return 0;
+    }
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 

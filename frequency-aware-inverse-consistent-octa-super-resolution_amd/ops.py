@@ -27,6 +27,8 @@ def act_code(a):
 
 
 def _c(t):
+    if not t.is_cuda:
+        raise _lib.KernelError("operand lives on %s: the HIP operators have no CPU/eager fallback" % t.device)
     return t if t.is_contiguous() else t.contiguous()
 
 

@@ -1,0 +1,123 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header declares, host-side logic
+(state_dict layout, init rule, replay buffer, LR lambda, parameter arena), and the product path refuses to
+run without a GPU instead of silently falling back."""
+import json
+import os
+import random
+import re
+
+import pytest
+import torch
+
+import faoctasr
+from faoctasr import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "faoctasr.h")).read()
+    declared = set(re.findall(r"\b(faoctasr_[a-z0-9_]+)\s*\(", header))
+    declared.discard("faoctasr_stream_t")
+    assert len(declared) >= 37
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "libfaoctasr.so does not export %s" % sym
+    # and the ctypes table binds exactly the declared set
+    assert set(_lib.declared_symbols()) == declared
+    assert lib.faoctasr_version() >= 100
+    assert lib.faoctasr_bn_workspace_floats(64) == 64 * 64 * 2
+    assert lib.faoctasr_conv_wpack_floats(0, 64, 64, 3, 3, 1, 1) > 64 * 64 * 9
+    assert lib.faoctasr_conv_wpack_floats(9, 64, 64, 3, 3, 1, 1) < 0          # unknown kind -> error code
+    assert b"unknown kind" in lib.faoctasr_last_error()
+
+
+def test_no_cpu_fallback():
+    """Host tensors must be rejected loudly (no eager/CPU path behind the operators)."""
+    with pytest.raises(faoctasr.KernelError):
+        faoctasr.ops.conv2d(torch.zeros(1, 1, 8, 8), torch.zeros(4, 1, 3, 3))
+    with pytest.raises(faoctasr.KernelError):
+        faoctasr.ops.batchnorm_train(torch.zeros(2, 4, 4, 4), torch.ones(4), torch.zeros(4))
+    with pytest.raises(faoctasr.KernelError):
+        faoctasr.high_pass(torch.zeros(1, 16, 16), 4)
+
+
+def test_state_dict_matches_reference_listing():
+    with open(os.path.join(GOLD, "state_dict_spec.json")) as f:
+        ref = json.load(f)
+    nets = {"A2B": faoctasr.NetworkA2B(), "B2A": faoctasr.NetworkB2A(), "D_A": faoctasr.FS_DiscriminatorA(1), "D_B": faoctasr.FS_DiscriminatorB(1)}
+    for k, n in nets.items():
+        sd = n.state_dict()
+        assert set(sd) == set(ref[k]), k
+        for key, t in sd.items():
+            assert list(t.shape) == ref[k][key], (k, key)
+    # live parameter counts: dead unet/unet_up/skip tensors are excluded from the optimizer arenas
+    live = {k: sum(p.numel() for _, p in faoctasr.live_parameters(n)) for k, n in nets.items()}
+    with open(os.path.join(GOLD, "golden_step.json")) as f:
+        assert live == json.load(f)["configs"][0]["live_params"]
+    assert live["A2B"] == 11162880 and live["B2A"] == 11290752
+
+
+def test_weights_init_normal_rule():
+    torch.manual_seed(0)
+    net = faoctasr.NetworkB2A()
+    bias_before = net.resnet.model[25].bias.detach().clone()
+    net.apply(faoctasr.weights_init_normal)
+    w = net.resnet.model[1].weight
+    assert abs(float(w.mean())) < 1e-3 and abs(float(w.std()) - 0.02) < 1e-3          # Conv*: N(0, 0.02)
+    bn = net.resnet.model[2]
+    assert abs(float(bn.weight.mean()) - 1.0) < 0.02 and float(bn.bias.abs().max()) == 0.0   # BatchNorm2d: N(1, 0.02), 0
+    assert torch.equal(net.resnet.model[25].bias.detach(), bias_before)                 # conv bias untouched (utils.py:66)
+
+
+def test_replay_buffer_and_lr_lambda():
+    random.seed(7)
+    buf = faoctasr.ReplayBuffer(max_size=3)
+    outs = []
+    for i in range(8):
+        x = torch.full((1, 1, 2, 2), float(i))
+        outs.append(float(buf.push_and_pop(x).mean()))
+    assert outs[:3] == [0.0, 1.0, 2.0]                      # pass-through while filling (utils.py:40-42)
+    assert len(buf.data) == 3
+    random.seed(7)
+    from oracle import octa_oracle as O
+    ob = O.ReplayBuffer(max_size=3)
+    assert outs == [float(ob.push_and_pop(torch.full((1, 1, 2, 2), float(i))).mean()) for i in range(8)]
+    lam = faoctasr.LambdaLR(50, 0, 10)
+    assert lam.step(0) == 1.0 and lam.step(10) == 1.0 and lam.step(30) == pytest.approx(0.5) and lam.step(50) == pytest.approx(0.0)
+    with pytest.raises(AssertionError):
+        faoctasr.LambdaLR(10, 0, 10)
+
+
+def test_param_arena_views_cpu():
+    """Flat arenas: parameters and gradients are views of two contiguous buffers (no kernel needed to check the layout)."""
+    lin = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    named = list(lin.named_parameters())
+    before = [p.detach().clone() for _, p in named]
+    arena = faoctasr.ParamArena(named, lr=1e-3)
+    assert arena.live_numel == sum(p.numel() for _, p in named)
+    assert arena.numel % 4 == 0 and all(o % 4 == 0 for o in arena.offsets)
+    for (_, p), b, o in zip(named, before, arena.offsets):
+        assert torch.equal(p.detach(), b)
+        assert p.data_ptr() == arena.flat.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == arena.grad.data_ptr() + 4 * o
+    lin(torch.randn(4, 3)).sum().backward()                       # autograd accumulates INTO the arena views
+    assert float(arena.grad.abs().sum()) > 0
+    arena.zero_grad()
+    assert float(arena.grad.abs().sum()) == 0 and named[0][1].grad.data_ptr() == arena.grad.data_ptr()
+
+
+def test_wavelet_module_interface_cpu():
+    f = faoctasr.DWTForward(J=1, wave="haar", mode="reflect")
+    assert set(dict(f.named_buffers())) == {"h0_col", "h1_col", "h0_row", "h1_row"}
+    assert tuple(f.h0_col.shape) == (1, 1, 2, 1) and tuple(f.h1_row.shape) == (1, 1, 1, 2)
+    from oracle import octa_oracle as O
+    st = O.make_state(O.spec_fs_discriminator("sum"), "D_A")
+    for k in ("h0_col", "h1_col", "h0_row", "h1_row"):
+        assert torch.allclose(getattr(f, k), st["DWT2." + k])
+    with pytest.raises(NotImplementedError):
+        faoctasr.DWTForward(J=1, wave="db4")
+    with pytest.raises(ValueError):
+        faoctasr.wavelets.mode_to_int("bogus")
+    assert faoctasr.wavelets.int_to_mode(faoctasr.wavelets.mode_to_int("reflect")) == "reflect"
