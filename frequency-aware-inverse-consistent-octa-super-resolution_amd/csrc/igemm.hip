@@ -483,6 +483,14 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
+    if (OW >= 24) {      // wide maps: LDS-patch weight gradient (atomics into dw, zeroed here unless accumulating)
+        if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
+            return fail(FAOCTASR_EHIP, "memset dw failed");
+        rc = launch_wgrad_patch(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
+                                (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        return launch_wgrad(x, dy, dw, g, (long)M * C * KH * KW, 1, (hipStream_t)stream);
+    }
     return launch_wgrad(x, dy, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
 }
 
@@ -519,6 +527,14 @@ int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, 
     // dw[c][m][t] = sum x[n][c][iy][ix] * dy[n][m][iy*s-p+kh][..]: conv-wgrad with source dy (M channels) and "dY" = x
     int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
     if (rc) return rc;
+    if (IW >= 24) {
+        if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
+            return fail(FAOCTASR_EHIP, "memset dw failed");
+        rc = launch_wgrad_patch(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,
+                                (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        return launch_wgrad(dy, x, dw, g, (long)M * C * KH * KW, 1, (hipStream_t)stream);
+    }
     return launch_wgrad(dy, x, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
 }
 

@@ -35,5 +35,7 @@ int patch_geom_from(const IgemmGeom& f, PatchGeom& g);
 long patch_pack_floats(const PatchGeom& g);
 int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s);
 int launch_patch(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s);
+int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
+                       int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 
 }  // namespace faoctasr

@@ -113,15 +113,16 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
     const float invPW = 1.0f / (float)PW, invPHW = 1.0f / (float)PHW;
 
 
-    // per-thread patch element geometry is chunk-invariant: decode once.  poff = offset inside the chunk's input planes
-    // (or -1: zero padding / beyond the patch); tailmask bit i = element i's channel still exists in the LAST chunk
-    int poff[NPV];
-    unsigned tailmask = 0;
-    const int c_last = g.C - (nchunks - 1) * KC;        // channels present in the last chunk
+    // per-thread patch element geometry is chunk-invariant: decode once into a byte offset inside the chunk's input
+    // planes.  Loads go through a buffer descriptor whose num_records ends at the last real channel, so an offset past it
+    // returns 0: that implements zero padding (offset OOB), the channel tail of the last chunk and masked tile pixels
+    // without selects, and the offsets need one VGPR each instead of a 64-bit address pair.
+    constexpr unsigned OOB = 0x7fffffffu;
+    unsigned poff[NPV];
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
         const int e = tid + 256 * i;
-        int off = -1;
+        unsigned off = OOB;
         if (e < npatch) {
             const int c = (int)(((float)e + 0.5f) * invPHW);
             const int r = e - c * PHW;
@@ -133,8 +134,7 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
                 iy = reflect_idx_p(iy, IH);
                 ix = reflect_idx_p(ix, IW);
             }
-            if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = c * (int)chw + iy * IW + ix;
-            if (c < c_last) tailmask |= 1u << i;
+            if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = 4u * (unsigned)(c * (int)chw + iy * IW + ix);
         }
         poff[i] = off;
     }
@@ -153,25 +153,21 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
                                              (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
         }
     };
-    // raw prefetch: every lane issues its load (address clamped to the plane start when masked); the zero-select is
-    // deferred to store_patch so the compiler has no reason to wait for the loads before the MFMA loop
     auto load_patch = [&](int chunk) {
-        const float* xc = xin + (long)chunk * KC * chw;
-        const unsigned live = (chunk == nchunks - 1) ? tailmask : 0xffffffffu;
+        const int c0 = chunk * KC;
+        const long bytes = (long)(g.C - c0) * chw * 4;
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)c0 * chw), 0,
+                                                           (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NPV; ++i) {
-            const bool ok = poff[i] >= 0 && ((live >> i) & 1u);
-            pv[i] = xc[ok ? poff[i] : 0];
-        }
+        for (int i = 0; i < NPV; ++i) pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i], 0, 0));
     };
     auto store_patch = [&](int buf, int chunk) {
+        (void)chunk;
         float* dst = P_lds + buf * npatch;
-        const unsigned live = (chunk == nchunks - 1) ? tailmask : 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < NPV; ++i) {
             const int e = tid + 256 * i;
-            const bool ok = poff[i] >= 0 && ((live >> i) & 1u);
-            if (e < npatch) dst[e] = ok ? pv[i] : 0.f;
+            if (e < npatch) dst[e] = pv[i];
         }
     };
 

@@ -1,0 +1,307 @@
+// LDS-patch weight gradient for gfx950 (f32 MFMA 32x32x2), the wide-map counterpart of igemm_wgrad_kernel.
+//
+//   dW[m][(c,t)] = sum over pixels p=(n,y,x) of  dY[n][m][y][x] * X[n][c][y*S + kh_t - pad][x*S + kw_t - pad]
+//
+// GEMM with the PIXELS as the reduction dimension.  A block owns 64 output channels (rows m) x CT = WN*NI*32
+// flattened (c,t) columns and walks a range of pixel tiles (TH=2 rows x 32 pixels of one image).  Per tile it stages
+//   * the dY tile [64][64 pixels] (A operand: A[i=m][k=pixel]) and
+//   * the input patch of the channels its columns touch, [(c)][(TH-1)*S+KH][31*S+KW] (zero / reflect padding
+//     resolved while staging),
+// once in LDS; the B fragment of column j=(c,t) for pixel p is then patch[c][row(p)*S+kh][col(p)*S+kw], i.e. a
+// per-lane constant base plus a wave-uniform pixel offset: no im2col arithmetic in the MFMA loop, and dY / X are read
+// about once per column slab instead of once per 64 columns.  Fragment reads are software pipelined with hand-counted
+// waits (see igemm_patch.hip).  Partial sums go to the gradient arena with fp32 atomics (split over pixel ranges).
+#include "common.h"
+#include "igemm_geom.h"
+
+namespace faoctasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradGeom {
+    int N, C, IH, IW;        // gathered tensor X
+    int M, OH, OW;           // dY
+    int S, pad, KH, KW, reflect;
+    long wsm, wsc;           // dW element strides for row m / gathered channel c (tap index contiguous)
+    int ncols;               // C * KH * KW
+    int tiles_per_img, tiles_x;
+    int tiles_per_block;     // pixel tiles reduced by one block
+};
+
+__device__ __forceinline__ int reflect_idx_w(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+__device__ __forceinline__ void ds_read_w(float& dst, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr)); }
+
+constexpr int WG_TH = 2, WG_PIX = WG_TH * 32, WG_LDY = WG_PIX + 1, WG_MT = 64;
+constexpr int WG_NPV = 20;                    // patch elements staged per thread
+
+// 256 threads = 4 waves as 2 (rows m) x 2 (columns): a wave owns 32 rows x NI*32 columns, so every SIMD of the CU hosts
+// exactly one wave of each resident block (3-wave blocks left two SIMDs doubly loaded and ran ~2x slower).
+template <int NI>
+__global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, const WgradGeom g) {
+    constexpr int NT = 256, CT = 2 * NI * 32, MI = 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int T = g.KH * g.KW;
+    const int col0 = blockIdx.x * CT;
+    const int m0 = blockIdx.y * WG_MT;
+    const int c_lo = col0 / T;
+    int c_hi = (col0 + CT - 1) / T;
+    c_hi = c_hi < g.C ? c_hi : g.C - 1;
+    const int NCH = c_hi - c_lo + 1;
+    const int S = g.S;
+    const int PH = (WG_TH - 1) * S + g.KH, PW = 31 * S + g.KW, PHW = PH * PW;
+    const int npatch = NCH * PHW;
+    const int ndy = WG_MT * WG_PIX;
+    constexpr int NDY = (WG_MT * WG_PIX + NT - 1) / NT;               // dY elements staged per thread
+    float* const D_lds = reinterpret_cast<float*>(smem);              // 2 x [64][65]
+    float* const P_lds = D_lds + 2 * WG_MT * WG_LDY;                  // 2 x [NCH][PH][PW]
+    const long ohw = (long)g.OH * g.OW, ihw = (long)g.IH * g.IW;
+
+    const long ntiles = (long)g.N * g.tiles_per_img;
+    const long tile0 = (long)blockIdx.z * g.tiles_per_block;
+    long tile1 = tile0 + g.tiles_per_block;
+    tile1 = tile1 < ntiles ? tile1 : ntiles;
+    if (tile0 >= tile1) return;
+
+    // Staging loads go through buffer descriptors (SRD in SGPRs, one 32-bit offset VGPR per load): an offset past
+    // num_records returns 0, which implements image-border zero padding, the M / C tails and masked tile pixels without
+    // selects.  (LDS-DMA was tried for these ragged tiles: 4-byte pieces are instruction-bound, ~1.4x slower.)
+    constexpr unsigned OOB = 0x7fffffffu;
+    // patch element e = tid + NT*i -> (c, py, px), decoded ONCE (float-reciprocal division is too expensive per tile):
+    // packed c<<16 | py<<8 | px, or -1 past the patch
+    int pdec[WG_NPV];
+    {
+        const float invPHW = 1.0f / (float)PHW, invPW = 1.0f / (float)PW;
+#pragma unroll
+        for (int i = 0; i < WG_NPV; ++i) {
+            const int e = tid + NT * i;
+            int d = -1;
+            if (e < npatch) {
+                const int c = (int)(((float)e + 0.5f) * invPHW);
+                const int r = e - c * PHW;
+                const int py = (int)(((float)r + 0.5f) * invPW);
+                d = (c << 16) | (py << 8) | (r - py * PW);
+            }
+            pdec[i] = d;
+        }
+    }
+    float dv[NDY], pv[WG_NPV];
+
+    auto tile_coords = [&](long tile, int& n, int& y0, int& x0) {
+        n = (int)(tile / g.tiles_per_img);
+        const int r = (int)(tile - (long)n * g.tiles_per_img);
+        const int ty = r / g.tiles_x;
+        y0 = ty * WG_TH;
+        x0 = (r - ty * g.tiles_x) * 32;
+    };
+    auto load_tile = [&](long tile) {
+        int n, y0, x0;
+        tile_coords(tile, n, y0, x0);
+        const float* dyp = dy + ((long)n * g.M + m0) * ohw;
+        const long dy_bytes = (long)(g.M - m0) * ohw * 4;
+        const auto dsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dyp), 0, (int)(dy_bytes < 0x7ffffff0L ? dy_bytes : 0x7ffffff0L), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = tid + NT * i;
+            const int m = e >> 6, p = e & 63;
+            const int yy = y0 + (p >> 5), xx = x0 + (p & 31);
+            const bool ok = e < ndy && yy < g.OH && xx < g.OW;
+            const unsigned off = ok ? 4u * (unsigned)(m * (int)ohw + yy * g.OW + xx) : OOB;
+            dv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dsrd, off, 0, 0));
+        }
+        const float* xp = x + ((long)n * g.C + c_lo) * ihw;
+        const long x_bytes = (long)(g.C - c_lo) * ihw * 4;
+        const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xp), 0, (int)(x_bytes < 0x7ffffff0L ? x_bytes : 0x7ffffff0L), 0x00020000);
+        const int iy0 = y0 * S - g.pad, ix0 = x0 * S - g.pad;
+#pragma unroll
+        for (int i = 0; i < WG_NPV; ++i) {
+            const int d = pdec[i];
+            int iy = iy0 + ((d >> 8) & 0xff), ix = ix0 + (d & 0xff);
+            // branch-free reflection (selected by the uniform flag): i -> |i|, then 2n-2-i past the end
+            const int ry = iy < 0 ? -iy : iy, rx = ix < 0 ? -ix : ix;
+            const int ry2 = ry >= g.IH ? 2 * g.IH - 2 - ry : ry, rx2 = rx >= g.IW ? 2 * g.IW - 2 - rx : rx;
+            iy = g.reflect ? ry2 : iy;
+            ix = g.reflect ? rx2 : ix;
+            const bool ok = d >= 0 && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            const unsigned off = ok ? 4u * (unsigned)((d >> 16) * (int)ihw + iy * g.IW + ix) : OOB;
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, off, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* dd = D_lds + buf * WG_MT * WG_LDY;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int e = tid + NT * i;
+            if (e < ndy) dd[(e >> 6) * WG_LDY + (e & 63)] = dv[i];
+        }
+        float* pd = P_lds + buf * npatch;
+#pragma unroll
+        for (int i = 0; i < WG_NPV; ++i) {
+            const int e = tid + NT * i;
+            if (e < npatch) pd[e] = pv[i];
+        }
+    };
+
+    // this lane's NI columns: base offset of (c,t) inside the patch
+    int bbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        int col = col0 + (wn * NI + ni) * 32 + l31;
+        col = col < g.ncols ? col : g.ncols - 1;                       // clamped columns are never written back
+        const int c = col / T, t = col - c * T;
+        const int kh = t / g.KW, kw = t - kh * g.KW;
+        bbase[ni] = (c - c_lo) * PHW + kh * PW + kw + lh * S;          // lh selects the second pixel of the pair
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    load_tile(tile0);
+    store_tile(0);
+    __syncthreads();
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const int cur = (int)(tile - tile0) & 1;
+        if (tile + 1 < tile1) load_tile(tile + 1);
+        // A fragment: D[m = l31 (+32)][pixel 2s + lh]; B fragment: P[bbase + pixel offset]
+        unsigned Aa = lds0 + 4u * (unsigned)(cur * WG_MT * WG_LDY + (wm * 32 + l31) * WG_LDY + lh);
+        unsigned Ba[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Ba[ni] = lds0 + 4u * (unsigned)(2 * WG_MT * WG_LDY + cur * npatch + bbase[ni]);
+        const unsigned b_step = 8u * (unsigned)S, b_rowfix = 4u * (unsigned)(S * PW - 32 * S);
+        float a0[MI], b0[NI], a1[MI], b1[NI];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        auto rd = [&](float (&a)[MI], float (&b)[NI]) {
+            ds_read_w(a[0], Aa);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) ds_read_w(b[ni], Ba[ni]);
+        };
+        auto adv = [&](int s_next) {                                     // s_next = index of the step being fetched
+            Aa += 8u;
+            const unsigned fix = ((s_next & 15) == 0) ? b_rowfix : 0u;   // first pixel pair of the next row
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) Ba[ni] += b_step + fix;
+        };
+        rd(a0, b0);
+        for (int s = 0; s < WG_PIX / 2; s += 2) {
+            adv(s + 1);
+            rd(a1, b1);
+            if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
+            else if constexpr (NI == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]));
+            else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0[0]), "+v"(b0[0]));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            adv(s + 2);
+            rd(a0, b0);                                                   // the last one runs past the tile: never used
+            if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]));
+            else if constexpr (NI == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]));
+            else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[0]), "+v"(b1[0]));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // retire the run-past reads
+        if (tile + 1 < tile1) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: row m from the register index, column from the lane
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = col0 + (wn * NI + ni) * 32 + l31;
+        if (col >= g.ncols) continue;
+        const int c = col / T, t = col - c * T;
+        float* dst = dw + (long)c * g.wsc + t;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + (wm + mi) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+                if (m < g.M) atomicAdd(dst + (long)m * g.wsm, acc[mi][ni][rr]);
+            }
+    }
+}
+
+template <int NI>
+static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hipStream_t s) {
+    constexpr int CT = 2 * NI * 32, NT = 256;
+    const int T = g.KH * g.KW;
+    int nch = CT / T + 2;
+    nch = nch < g.C ? nch : g.C;
+    const int PH = (WG_TH - 1) * g.S + g.KH, PW = 31 * g.S + g.KW;
+    const long npatch = (long)nch * PH * PW;
+    if (npatch > (long)NT * WG_NPV) return false;
+    const size_t lds = (2 * (size_t)WG_MT * WG_LDY + 2 * (size_t)npatch) * 4 + 1024;
+    if (lds > 79 * 1024) return false;                                  // two blocks per CU
+    const int gx = (g.ncols + CT - 1) / CT, gy = (g.M + WG_MT - 1) / WG_MT;
+    const long ntiles = (long)g.N * g.tiles_per_img;
+    // one residency round: 256 CUs x 2 blocks; split the pixel tiles so that gx*gy*slices just fits
+    long slices = 512 / ((long)gx * gy);
+    if (slices < 1) slices = 1;
+    if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
+    g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
+    slices = (ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+    auto k = wgrad_patch_kernel<NI>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(gx, gy, (unsigned)slices), dim3(NT), lds, s, x, dy, dw, g);
+    return true;
+}
+
+// returns 1 when launched, 0 when the shape is left to the flat kernel, <0 on error.  dw must already be zeroed / hold
+// the running gradient (accumulation is by atomics).
+int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
+                       int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
+    // stride-2 layers (large patches, small slabs) measured faster on the flat kernel
+    if (OW < 24 || stride != 1 || KH > 15 || KW > 15 || C * KH * KW < 64) return 0;
+    WgradGeom g;
+    g.N = N; g.C = C; g.IH = IH; g.IW = IW; g.M = M; g.OH = OH; g.OW = OW; g.S = stride; g.pad = pad; g.KH = KH; g.KW = KW;
+    g.reflect = reflect; g.wsm = wsm; g.wsc = wsc; g.ncols = C * KH * KW;
+    g.tiles_x = (OW + 31) / 32;
+    g.tiles_per_img = g.tiles_x * ((OH + WG_TH - 1) / WG_TH);
+    g.tiles_per_block = 1;
+    // column slab = 2 * NI * 32: minimise padded columns, ties to the wider slab (dY / X are re-read once per slab)
+    const int n = g.ncols;
+    // cost model: padded MFMA work, plus the per-tile staging of the dY tile amortised over NI column tiles
+    int order[4] = {4, 3, 2, 1};
+    double best_cost = -1;
+    int best = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int ct = 64 * order[i];
+        const double cost = (double)((n + ct - 1) / ct) * ct * (1.0 + 1.5 / order[i]);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = order[i]; }
+    }
+    bool ok = false;
+    for (int ni = best; ni >= 1 && !ok; --ni) {
+        if (ni == 4) ok = wg_try<4>(x, dy, dw, g, s);
+        else if (ni == 3) ok = wg_try<3>(x, dy, dw, g, s);
+        else if (ni == 2) ok = wg_try<2>(x, dy, dw, g, s);
+        else ok = wg_try<1>(x, dy, dw, g, s);
+    }
+    if (!ok) return 0;
+    const int rc = check_launch("wgrad_patch");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+}  // namespace faoctasr
