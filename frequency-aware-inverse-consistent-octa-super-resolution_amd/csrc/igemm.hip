@@ -457,6 +457,8 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: kernel (%d x %d) larger than padded input (%d x %d)", KH, KW, IH + 2 * pad, IW + 2 * pad);
+    if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
+        return launch_conv_m1_fwd(x, w, bias, y, N, C, IH, IW, KH, KW, pad, act, slope, (hipStream_t)stream);
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
@@ -480,6 +482,8 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");
+    if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
+        return launch_conv_m1_wgrad(x, dy, dw, N, C, IH, IW, KH, KW, pad, accumulate, (hipStream_t)stream);
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;

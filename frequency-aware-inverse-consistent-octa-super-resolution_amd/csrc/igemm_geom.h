@@ -38,4 +38,10 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 
+// single-output-channel 'same' stride-1 convolution on the VALU (conv_m1.hip)
+int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int KH, int KW, int pad,
+                       int act, float slope, hipStream_t stream);
+int launch_conv_m1_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int KH, int KW, int pad, int accumulate,
+                         hipStream_t st);
+
 }  // namespace faoctasr

@@ -450,15 +450,16 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
     return check_launch("igemm_patch");
 }
 
-// split K when the tile grid alone cannot fill 256 CUs twice over (no fused activation in that mode)
+// split K when the tile grid alone cannot fill the chip.  Residency is 2 blocks per CU (LDS budget) = 512 slots: a grid
+// slightly above a multiple of 512 runs a nearly empty extra round, so the split is sized to land just under one round.
 static int pick_ksplit(const PatchGeom& g, long blocks, int act) {
-    if (act != FAOCTASR_ACT_NONE || blocks >= 384) return 1;
+    if (act != FAOCTASR_ACT_NONE || blocks > 256) return 1;
     int minchunks = 1 << 30;
     for (int p = 0; p < g.nphase; ++p) {
         const int nc = (g.C + g.kc[p] - 1) / g.kc[p];
         minchunks = nc < minchunks ? nc : minchunks;
     }
-    int ks = (int)((640 + blocks - 1) / blocks);
+    int ks = (int)(512 / blocks);
     if (ks > minchunks / 2) ks = minchunks / 2;
     return ks < 1 ? 1 : ks;
 }
