@@ -8,6 +8,7 @@ from . import _lib, ops
 from ._lib import KernelError
 from .model import (Discriminator, FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A, ResidualBlock, ResnetBlock,
                     ResnetGenerator, TVLoss, UnetGenerator, UnetSkipConnectionBlock, shallowNet)
+from .evaluate import evaluate_pairs, super_resolve
 from .ssim import SSIM, ssim
 from .train import ParamArena, TrainStep, live_parameters
 from .utils import (LambdaLR, ReplayBuffer, frequency_split, high_pass, low_pass, psnr, set_requires_grad, weights_init_normal)

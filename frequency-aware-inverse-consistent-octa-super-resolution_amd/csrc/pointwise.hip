@@ -230,6 +230,30 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const float* __restric
     }
 }
 
+// inference-mode BatchNorm: per-channel affine from the running statistics
+__global__ void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ y, int C, int HW,
+                                   long total, float eps, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)((i / HW) % C);
+        const float sc = (gamma ? gamma[c] : 1.f) / sqrtf(rvar[c] + eps);
+        y[i] = act_apply((x[i] - rmean[c]) * sc + (beta ? beta[c] : 0.f), act, slope);
+    }
+}
+
+__global__ void bn_eval_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ gamma,
+                                   const float* __restrict__ rvar, float* __restrict__ dx, int C, int HW, long total, float eps, int act,
+                                   float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)((i / HW) % C);
+        float g = dy[i];
+        if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[i], act, slope);
+        dx[i] = g * (gamma ? gamma[c] : 1.f) / sqrtf(rvar[c] + eps);
+    }
+}
+
 static void norm_split(long L, int R, int& S, long& per) {
     // enough blocks to fill 256 CUs a few times over, each block >= 4096 elements
     long want = (1024 + R - 1) / R;
@@ -624,6 +648,27 @@ int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y
                                  int act, float slope, int accumulate_affine, float* workspace, faoctasr_stream_t stream) {
     return norm_bwd(x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, dres, N, C, C, HW, act, slope, accumulate_affine,
                     workspace, (hipStream_t)stream);
+}
+
+int faoctasr_batchnorm_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                float* y, int N, int C, int HW, float eps, int act, float slope, faoctasr_stream_t stream) {
+    if (!x || !y || !running_mean || !running_var) return fail(FAOCTASR_EINVAL, "batchnorm_eval_fwd: null pointer");
+    const long total = (long)N * C * HW;
+    if (total <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, running_mean,
+                       running_var, y, C, HW, total, eps, act, slope);
+    return check_launch("bn_eval_fwd");
+}
+
+int faoctasr_batchnorm_eval_bwd(const float* dy, const float* y, const float* gamma, const float* running_var, float* dx, int N, int C, int HW,
+                                float eps, int act, float slope, faoctasr_stream_t stream) {
+    if (!dy || !dx || !running_var) return fail(FAOCTASR_EINVAL, "batchnorm_eval_bwd: null pointer");
+    if (act != FAOCTASR_ACT_NONE && !y) return fail(FAOCTASR_EINVAL, "batchnorm_eval_bwd: activation mask needs the forward output");
+    const long total = (long)N * C * HW;
+    if (total <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, dy, y, gamma, running_var, dx, C,
+                       HW, total, eps, act, slope);
+    return check_launch("bn_eval_bwd");
 }
 
 // InstanceNorm2d = the same kernels over R = N*C rows of one image each (workspace: faoctasr_bn_workspace_floats(N*C))

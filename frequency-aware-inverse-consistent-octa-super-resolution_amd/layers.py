@@ -58,6 +58,10 @@ class ConvTranspose2d(nn.Module):
 
 
 class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d (affine, track_running_stats).  Training: batch statistics, fused activation / residual; eval: running
+    statistics (the inference path).  ``num_batches_tracked`` is counted on the host and written into the buffer when the
+    state_dict is taken (one tiny device kernel per BN call otherwise: 243 per train step)."""
+
     def __init__(self, num_features, eps=1e-5, momentum=0.1):
         super().__init__()
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
@@ -66,12 +70,31 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0
+
+    def _flush_counter(self):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, act=None, slope=0.2, residual=None):
         if not self.training:
-            raise NotImplementedError("BatchNorm2d eval mode (running statistics) belongs to the inference path "
-                                      "(SURVEY.md 8f-2) and is not built yet")
-        self.num_batches_tracked += 1
+            y = ops.batchnorm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, None if residual is not None else act,
+                                   slope)
+            if residual is not None:
+                y = ops.add(y, residual)
+                if act:
+                    y = ops.activation(y, act, slope)
+            return y
+        self._pending_batches += 1
         return ops.batchnorm_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
                                    residual)
 

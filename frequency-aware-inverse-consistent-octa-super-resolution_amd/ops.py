@@ -218,6 +218,7 @@ class _BatchNormTrain(Function):
         ctx.g_ref, ctx.b_ref = gamma, beta
         ctx.cfg = (act, slope, residual is not None)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for `stats` on every backward
         return y, stats
 
     @staticmethod
@@ -246,6 +247,35 @@ class _BatchNormTrain(Function):
              ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
              N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+class _BatchNormEval(Function):
+    """Inference-mode BatchNorm2d (running statistics): y = act(gamma * (x - mean) / sqrt(var + eps) + beta)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, act, slope):
+        x = _c(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        call("batchnorm_eval_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(y), N, C, H * W, eps, act, slope,
+             stream_ptr())
+        ctx.save_for_backward(gamma, running_var, y if act else None)
+        ctx.cfg = (eps, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        gamma, rv, y = ctx.saved_tensors
+        eps, act, slope = ctx.cfg
+        dy = _c(dy)
+        N, C, H, W = dy.shape
+        dx = torch.empty_like(dy)
+        call("batchnorm_eval_bwd", ptr(dy), ptr(y), ptr(gamma), ptr(rv), ptr(dx), N, C, H * W, eps, act, slope, stream_ptr())
+        return dx, None, None, None, None, None, None, None
+
+
+def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, act=None, slope=0.2):
+    return _BatchNormEval.apply(x, gamma, beta, running_mean, running_var, float(eps), act_code(act), float(slope))
 
 
 def batchnorm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=None, slope=0.2, residual=None):

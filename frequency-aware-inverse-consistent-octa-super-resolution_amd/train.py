@@ -184,6 +184,16 @@ class TrainStep:
             out["tensors"] = {k: v.detach() for k, v in o.items()}
         return out
 
+    # -- learning-rate schedule (train.py:105-110,287-288) -------------------------------------
+    def set_lr(self, lr_G, lr_D=None):
+        self.opt_G.lr = float(lr_G)
+        self.opt_D.lr = float(lr_G if lr_D is None else lr_D)
+
+    def lr_step(self, base_lr, lr_lambda, epoch):
+        """torch.optim.lr_scheduler.LambdaLR semantics: lr = base_lr * lr_lambda(epoch) for both optimizers
+        (``lr_lambda`` e.g. ``faoctasr.LambdaLR(n_epochs, offset, decay_epoch).step``)."""
+        self.set_lr(base_lr * lr_lambda(epoch))
+
     def grad_norms(self):
         """Per-network gradient L2 norms (diagnostics / parity tests; host-side reduction)."""
         r = {}

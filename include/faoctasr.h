@@ -89,6 +89,13 @@ int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y
                                  float* dx, float* dgamma, float* dbeta, float* dres,
                                  int N, int C, int HW, int act, float slope, int accumulate_affine,
                                  float* workspace, faoctasr_stream_t stream);
+/* nn.BatchNorm2d in eval mode (running statistics): the inference path, utils.py:186,221 `model.eval()`.
+ * y = act(gamma*(x-running_mean)/sqrt(running_var+eps)+beta); the backward gives dx only (statistics are constants). */
+int faoctasr_batchnorm_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float* y, int N, int C, int HW, float eps, int act, float slope,
+                                faoctasr_stream_t stream);
+int faoctasr_batchnorm_eval_bwd(const float* dy, const float* y, const float* gamma, const float* running_var, float* dx,
+                                int N, int C, int HW, float eps, int act, float slope, faoctasr_stream_t stream);
 /* InstanceNorm2d (named by north_star; not on the reference's path): per-(n,c) statistics;
  * save_mean/save_invstd have N*C entries, workspace faoctasr_bn_workspace_floats(N*C) floats. */
 int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y,

@@ -158,3 +158,27 @@ def test_extension_terms_vs_oracle(fa, O):
     gn, go = ts.grad_norms(), S.grad_norms()
     for k in ("A2B", "B2A"):
         assert gn[k] == pytest.approx(go[k], rel=2e-3), k
+
+
+def test_inference_path_eval_mode(fa, O):
+    """generator forward with BatchNorm on running statistics (`model.eval()`, utils.py:186) vs the oracle."""
+    nets = build_nets(fa, O)
+    a, _ = O.synthetic_batch(2, 192, seed=5)
+    # make the running statistics non-trivial: one training forward on both sides
+    st = O.make_state(O.spec_network_a2b(), "A2B", 0)
+    hf_o, lf_o = O.freq_split(a, 10, 8)
+    with torch.no_grad():
+        O.network_a2b(O.Net(st, train=True), lf_o, hf_o)
+        hf, lf = fa.frequency_split(a.cuda(), 10, 8)
+        nets["A2B"](lf, hf)
+        ref = O.network_a2b(O.Net(st, train=False), lf_o, hf_o)[2]
+    out = fa.super_resolve(nets["A2B"], a.cuda())
+    assert not nets["A2B"].training
+    close(out, ref, rtol=1e-3, atol=2e-4)
+    m = fa.evaluate_pairs(nets["A2B"], [(a[:1].cuda(), a[1:].cuda())])
+    assert set(m) == {"psnr", "ssim", "mse", "nmi"} and m["mse"] > 0
+    assert m["psnr"] == pytest.approx(O.psnr(fa.super_resolve(nets["A2B"], a[:1].cuda()).cpu(), a[1:]), rel=1e-6)
+    # LR schedule hook (train.py:105-110): linear decay to 0 after decay_epoch
+    ts = fa.TrainStep(nets["A2B"], nets["B2A"], nets["D_A"], nets["D_B"])
+    ts.lr_step(1.3e-4, fa.LambdaLR(50, 0, 10).step, 30)
+    assert ts.opt_G.lr == pytest.approx(0.65e-4) and ts.opt_D.lr == pytest.approx(0.65e-4)
