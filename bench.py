@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config 2: 8)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+                    help="conv contraction: exact fp32 MFMA (default, the headline) or bf16x3 split operands on the bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -124,7 +126,7 @@ def main():
     torch.manual_seed(0)
     import random
     random.seed(1234 + rank)
-    ts = faoctasr.TrainStep(device=device, distributed=distributed)
+    ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision)
     if distributed:                              # identical replicas: broadcast rank 0's arenas and buffers
         for t in (ts.opt_G.flat, ts.opt_D.flat):
             dist.broadcast(t, 0)
@@ -191,7 +193,8 @@ def main():
             cpu = cpu_baseline(H)
         line = {"metric": "train-step images/sec (G+D fwd+bwd) on 256x256 OCTA", "value": round(value, 3), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 split MFMA (fwd+dgrad), f32 wgrad", "data": "synthetic",
                 "config": {"workload": "%dx%dx1 OCTA pairs, batch %d per GPU, fp32, full G+D train step "
                                        "(4 frequency splits, 6 G fwd, 6 D fwd, 3 backward, 2 AdamW)" % (H, H, B),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "loss_G": round(loss_G, 5)},

@@ -405,8 +405,14 @@ static int launch_wgrad(const float* x, const float* dy, float* dw, IgemmGeom& g
 static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || !b || !c; }
 
 // wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
+// precision: 0 = exact f32 MFMA; 2 = bf16x3 split operands on the bf16 MFMA where the layer shape allows it
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
-                      int wpack_state, hipStream_t s) {
+                      int wpack_state, int precision, hipStream_t s) {
+    if (precision != 0 && precision != 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 2 = bf16x3)", precision);
+    if (wpack && wpack_state && precision == 2) {
+        const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+    }
     if (wpack && wpack_state) {
         PatchGeom pg;
         int rc = patch_geom_from(g, pg);
@@ -421,10 +427,15 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
     return launch_gather(x, w, bias, y, g, act, slope, s);
 }
 
-static long wpack_floats(IgemmGeom& g) {
+static long wpack_floats(IgemmGeom& g, int precision) {
     PatchGeom pg;
     if (patch_geom_from(g, pg)) return 0;
-    return patch_pack_floats(pg);
+    long n = patch_pack_floats(pg);
+    if (precision == 2) {
+        const long m = split_pack_floats_for(g);
+        n = m > n ? m : n;
+    }
+    return n;
 }
 
 }  // namespace faoctasr
@@ -434,7 +445,7 @@ using namespace faoctasr;
 extern "C" {
 
 // kind: 0 conv2d fwd, 1 conv2d dgrad, 2 conv_transpose2d fwd, 3 conv_transpose2d dgrad.  (C, M) as in the matching call.
-long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad) {
+long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad, int precision) {
     IgemmGeom g;
     const long kk = (long)KH * KW;
     // spatial sizes do not enter the packed layout; use a nominal 64x64 grid
@@ -447,12 +458,12 @@ long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stri
         default: return fail(FAOCTASR_EINVAL, "conv_wpack_floats: unknown kind %d", kind);
     }
     if (rc) return rc;
-    return wpack_floats(g);
+    return wpack_floats(g, precision);
 }
 
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,
                         int KH, int KW, int stride, int pad, int reflect, int act, float slope, float* wpack, int wpack_state,
-                        faoctasr_stream_t stream) {
+                        int precision, faoctasr_stream_t stream) {
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv2d_fwd: null pointer");
     if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
@@ -462,11 +473,11 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream);
 }
 
 int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW,
-                          int stride, int pad, float* wpack, int wpack_state, faoctasr_stream_t stream) {
+                          int stride, int pad, float* wpack, int wpack_state, int precision, faoctasr_stream_t stream) {
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
@@ -474,7 +485,7 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
     // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
     int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream);
 }
 
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
@@ -500,7 +511,7 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
 
 int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW,
                                   int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope, float* wpack,
-                                  int wpack_state, faoctasr_stream_t stream) {
+                                  int wpack_state, int precision, faoctasr_stream_t stream) {
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: bad shape");
@@ -508,11 +519,11 @@ int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* b
     // w[c][m][t]: m stride = KK, c stride = M*KK
     int rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, (long)KH * KW, (long)M * KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream);
 }
 
 int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH,
-                                    int KW, int stride, int pad, int out_pad, float* wpack, int wpack_state,
+                                    int KW, int stride, int pad, int out_pad, float* wpack, int wpack_state, int precision,
                                     faoctasr_stream_t stream) {
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_dgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
@@ -520,7 +531,7 @@ int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, 
     // dx[n][c][iy][ix] = sum_{m,t} dy[n][m][iy*s-p+kh][..] * w[c][m][t]: forward-mode gather over dy
     int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream);
 }
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,

@@ -1,0 +1,466 @@
+// Split-precision ("bf16x3") LDS-patch implicit GEMM for gfx950: fp32-parity convolutions on the bf16 matrix cores.
+//
+// Every fp32 operand is split into hi = bf16(x) and lo = bf16(x - hi); the product is accumulated in fp32 as
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (the dropped a_lo*b_lo term is ~2^-16 relative)
+// with three v_mfma_f32_32x32x16_bf16 per tile step.  The bf16 MFMA runs 16x the f32 MFMA rate, so the contraction is
+// ~5x faster than igemm_patch.hip at fp32-level accuracy: on the reference train step the losses move by <= 1.2e-4
+// relative and the gradient norms by <= 2.3e-4 (DESIGN.md "bf16x3"), inside the 1e-3 parity bar; plain bf16 operands
+// move them by 1.6e-2 / 12 % and are NOT offered.
+//
+// Structure (same tap-list geometry and phases as igemm_patch.hip):
+//   * K is walked in groups of 16 input channels (the MFMA's K) x a tap group; the MFMA k index is the channel, so the
+//     LDS patch is channel-innermost: P[plane][h = c/8][py][px][8 ch] bf16 -- a B fragment is one ds_read_b128.
+//   * patch staging: each thread loads the 8 channels of a (pixel, h) item with coalesced dword buffer loads (OOB -> 0 for
+//     padding / channel tail), splits to hi/lo with v_cvt_pk_bf16_f32 and writes two 16-byte vectors.
+//   * weights are pre-packed as Wp[plane][phase][g16][tap][h][Mpad][8 ch] bf16; a (tap-group, 64-row) slab is a run of
+//     1 KiB rows that LDS-DMA (global_load_lds_dwordx4) copies verbatim, double buffered against the MFMAs.
+//   * block = 4 waves side by side along the pixel rows (64 output channels x TH x 32 pixels), fragment reads software
+//     pipelined with hand-counted waits.
+#include "common.h"
+#include "igemm_geom.h"
+
+namespace faoctasr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SP_MT = 64;         // output channels per block
+constexpr int SP_NPI = 6;         // (pixel, h) items staged per thread
+
+struct SplitGeom {
+    int N, C, IH, IW, M, OH, OW, SI, SO, nphase, reflect, act;
+    float slope;
+    int Mpad;
+    long wsm, wsc;
+    int py[4], px[4], gh[4], gw[4], t0[5], oy0[4], ox0[4], span_y[4], span_x[4];
+    int tg[4];                     // taps per tap group
+    long pack_off[5];              // bf16 element offset of each phase inside a plane
+    long plane_stride;             // bf16 elements between the hi and the lo plane
+    int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
+};
+
+__device__ __forceinline__ int reflect_idx_s(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+__device__ __forceinline__ void ds_read_v8(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 W (arbitrary m / c strides, tap list) -> two bf16 planes in the LDS image order
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom g, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int ph = 0;
+        while (ph + 1 < g.nphase && i >= g.pack_off[ph + 1]) ++ph;
+        long li = i - g.pack_off[ph];
+        const int T = g.t0[ph + 1] - g.t0[ph];
+        const int j = (int)(li & 7); li >>= 3;
+        const int m = (int)(li % g.Mpad); li /= g.Mpad;
+        const int h = (int)(li & 1); li >>= 1;
+        const int t = (int)(li % T);
+        const int g16 = (int)(li / T);
+        const int c = g16 * 16 + 8 * h + j;
+        float v = 0.f;
+        if (m < g.M && c < g.C) v = w[(long)m * g.wsm + (long)c * g.wsc + (g.taps[g.t0[ph] + t] >> 16)];
+        const __bf16 hi = (__bf16)v;
+        wp[i] = hi;
+        wp[g.plane_stride + i] = (__bf16)(v - (float)hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int NI, int SI>
+__global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
+                                                           const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
+                                                           const int ksplit) {
+    constexpr int MI = 2, TH = 4 * NI;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
+    const int GH = g.gh[ph], GW = g.gw[ph];
+    const int tiles_x = (GW + 31) >> 5, tiles_y = (GH + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y;
+    const int bt = blockIdx.x;
+    if (bt >= g.N * tiles) return;
+    const int n = bt / tiles;
+    const int rt = bt - n * tiles;
+    const int ty = rt / tiles_x, tx = rt - ty * tiles_x;
+    const int t0 = g.t0[ph], T = g.t0[ph + 1] - t0, TG = g.tg[ph];
+    const int ntg = (T + TG - 1) / TG;
+    const int PH = (TH - 1) * SI + g.span_y[ph] + 1, PW = 31 * SI + g.span_x[ph] + 1, PHW = PH * PW;
+    const int ngroups = (g.C + 15) >> 4;
+    const int gps = (ngroups + ksplit - 1) / ksplit;
+    const int g0 = ks * gps;
+    const int g1 = (g0 + gps) < ngroups ? (g0 + gps) : ngroups;
+    if (g0 >= g1) return;
+    const int m0 = blockIdx.y * SP_MT;
+    const int IH = g.IH, IW = g.IW;
+    const long chw = (long)IH * IW;
+    const unsigned a_bytes = (unsigned)TG * 2048u;                      // per plane per buffer: TG taps x 2 halves x 64 rows x 16 B
+    const unsigned p_bytes = (unsigned)(2 * PHW) * 16u;                 // per plane per buffer
+    const unsigned A_base = 0, P_base = 4u * a_bytes;
+    const int y_base = ty * TH * SI + g.oy0[ph], x_base = tx * 32 * SI + g.ox0[ph];
+    const float* xin = x + (long)n * g.C * chw;
+
+    // tap offsets (in 16-byte pixel slots) in a lane table
+    int tapv = 0;
+    if (lane < T) {
+        const int tp = g.taps[t0 + lane];
+        tapv = (tp & 0xff) * PW + ((tp >> 8) & 0xff);
+    }
+
+    // patch items: item = h*PHW + pixel -> byte offset of channel 8h of that pixel inside the 16-channel group
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned poff[SP_NPI];
+    const int nitems = 2 * PHW;
+    const float invPW = 1.0f / (float)PW;
+#pragma unroll
+    for (int i = 0; i < SP_NPI; ++i) {
+        const int it = tid + 256 * i;
+        unsigned off = OOB;
+        if (it < nitems) {
+            const int h = it >= PHW ? 1 : 0;
+            const int p = it - h * PHW;
+            const int py = (int)(((float)p + 0.5f) * invPW);
+            const int px = p - py * PW;
+            int iy = y_base + py, ix = x_base + px;
+            if (g.reflect) {
+                iy = reflect_idx_s(iy, IH);
+                ix = reflect_idx_s(ix, IW);
+            }
+            if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = 4u * (unsigned)(8 * h * (int)chw + iy * IW + ix);
+        }
+        poff[i] = off;
+    }
+    float pv[SP_NPI][8];
+    const unsigned cstep = 4u * (unsigned)chw;
+
+    auto load_patch = [&](int grp) {
+        const long bytes = (long)(g.C - grp * 16) * chw * 4;
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
+                                                           (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < SP_NPI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
+    };
+    auto store_patch = [&](int buf) {
+        char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
+        char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
+#pragma unroll
+        for (int i = 0; i < SP_NPI; ++i) {
+            const int it = tid + 256 * i;
+            if (it < nitems) {
+                bf16x8 hv, lv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = pv[i][j];
+                    const __bf16 hb = (__bf16)v;
+                    hv[j] = hb;
+                    lv[j] = (__bf16)(v - (float)hb);
+                }
+                *reinterpret_cast<bf16x8*>(hi_p + it * 16) = hv;
+                *reinterpret_cast<bf16x8*>(lo_p + it * 16) = lv;
+            }
+        }
+    };
+    // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
+    auto issue_A = [&](int grp, int tgi, int abuf) {
+        const int tb = tgi * TG;
+        int nt = T - tb;
+        nt = nt < TG ? nt : TG;
+        const int rows = nt * 2;                                        // (tap, h)
+        for (int r = wave; r < 2 * rows; r += 4) {
+            const int plane = r >= rows ? 1 : 0;
+            const int rr = r - plane * rows;                            // tl*2 + h
+            const __bf16* src = wp + plane * g.plane_stride + g.pack_off[ph] +
+                                ((((long)grp * T + tb) * 2 + rr) * g.Mpad + m0) * 8 + lane * 8;
+            char* dst = smem + A_base + (abuf * 2 + plane) * a_bytes + rr * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned a_lane = (unsigned)(lh * 64 + l31) * 16u;                                     // + tl*2048, + mi*512
+    const unsigned b_lane = (unsigned)((lh * PH + (wave * NI) * SI) * PW + l31 * SI) * 16u;       // + tap*16, + ni*SI*PW*16
+    const unsigned b_row = (unsigned)(SI * PW) * 16u;
+
+    load_patch(g0);
+    issue_A(g0, 0, 0);
+    store_patch(0);
+    __syncthreads();
+
+    int slab = 0;
+    for (int grp = g0; grp < g1; ++grp) {
+        const int pbuf = (grp - g0) & 1;
+        if (grp + 1 < g1) load_patch(grp + 1);                          // held in registers across this group's tap groups
+        for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
+            const int abuf = slab & 1;
+            if (tgi + 1 < ntg) issue_A(grp, tgi + 1, abuf ^ 1);
+            else if (grp + 1 < g1) issue_A(grp + 1, 0, abuf ^ 1);
+            const int tb = tgi * TG;
+            int nt = T - tb;
+            nt = nt < TG ? nt : TG;
+            const unsigned Ah = lds0 + A_base + (abuf * 2 + 0) * a_bytes + a_lane, Al = Ah + a_bytes;
+            const unsigned Ph = lds0 + P_base + (pbuf * 2 + 0) * p_bytes + b_lane, Pl = Ph + p_bytes;
+            bf16x8 a0[MI][2], b0[NI][2], a1[MI][2], b1[NI][2];
+            auto rd = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], int tl) {
+                const unsigned ao = (unsigned)tl * 2048u;
+                const unsigned bo = 16u * (unsigned)__builtin_amdgcn_readlane(tapv, (tb + tl) & 63);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    ds_read_v8(a[mi][0], Ah + ao + mi * 512u);
+                    ds_read_v8(a[mi][1], Al + ao + mi * 512u);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    ds_read_v8(b[ni][0], Ph + bo + ni * b_row);
+                    ds_read_v8(b[ni][1], Pl + bo + ni * b_row);
+                }
+            };
+            auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);   // lo*hi
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);   // hi*lo
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);   // hi*hi
+                    }
+            };
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            rd(a0, b0, 0);
+            for (int tl = 0; tl < nt; tl += 2) {
+                rd(a1, b1, tl + 1);                                     // runs past the slab on the last odd step: never used
+                if constexpr (NI == 2)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
+                                 "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
+                                 "+v"(b0[0][1]));
+                mm(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tl + 1 >= nt) break;
+                rd(a0, b0, tl + 2);
+                if constexpr (NI == 2)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]), "+v"(b1[0][0]),
+                                 "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]), "+v"(b1[0][0]),
+                                 "+v"(b1[0][1]));
+                mm(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // retire run-ahead reads before LDS is rewritten
+            if (tgi == ntg - 1 && grp + 1 < g1) store_patch(pbuf ^ 1);
+            __syncthreads();                                             // next A slab landed (vmcnt(0)), next patch visible
+        }
+    }
+
+    // epilogue (as igemm_patch.hip)
+    const int mrow0 = m0 + 4 * lh;
+    if (bias && ks == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
+                const float bv = m < g.M ? bias[m] : 0.f;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][rr] += bv;
+            }
+    }
+    if (g.act == FAOCTASR_ACT_RELU) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = fmaxf(acc[mi][ni][rr], 0.f);
+    } else if (g.act == FAOCTASR_ACT_LRELU) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float v = acc[mi][ni][rr];
+                    acc[mi][ni][rr] = v > 0.f ? v : v * g.slope;
+                }
+    } else if (g.act == FAOCTASR_ACT_TANH) {
+        for (int mi = 0; mi < MI; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = tanhf(acc[mi][ni][rr]);
+    }
+    const long ohw = (long)g.OH * g.OW;
+    const int bo = tx * 32 + l31;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int ao = ty * TH + wave * NI + ni;
+        if (ao >= GH || bo >= GW) continue;
+        float* yo = y + (long)n * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
+                if (m < g.M) {
+                    if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
+                    else yo[(long)m * ohw] = acc[mi][ni][rr];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t SP_LDS_MAX = 156 * 1024;
+
+static size_t sp_lds(const SplitGeom& g, int NI, int SI) {
+    const int TH = 4 * NI;
+    size_t best = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int PH = (TH - 1) * SI + g.span_y[p] + 1, PW = 31 * SI + g.span_x[p] + 1;
+        const size_t b = 4 * (size_t)g.tg[p] * 2048 + 4 * (size_t)(2 * PH * PW) * 16 + 2048;
+        best = b > best ? b : best;
+    }
+    return best;
+}
+
+static bool sp_fits(const SplitGeom& g, int NI, int SI) {
+    const int TH = 4 * NI;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int PH = (TH - 1) * SI + g.span_y[p] + 1, PW = 31 * SI + g.span_x[p] + 1;
+        if (2 * PH * PW > 256 * SP_NPI) return false;
+    }
+    return sp_lds(g, NI, SI) <= SP_LDS_MAX;
+}
+
+// 1 when the layer can run on the split kernel (decided by the layer shape only)
+int split_geom_from(const IgemmGeom& f, SplitGeom& g) {
+    g = SplitGeom{};
+    g.N = f.N; g.C = f.C; g.IH = f.IH; g.IW = f.IW; g.M = f.M; g.OH = f.OH; g.OW = f.OW; g.SI = f.SI; g.SO = f.SO;
+    g.nphase = f.nphase; g.reflect = f.reflect; g.act = f.act; g.slope = f.slope; g.wsm = f.wsm; g.wsc = f.wsc;
+    if (g.C < 16 || (g.SI != 1 && g.SI != 2)) return 0;
+    for (int p = 0; p < 4; ++p) { g.py[p] = f.ph_py[p]; g.px[p] = f.ph_px[p]; g.gh[p] = f.ph_gh[p]; g.gw[p] = f.ph_gw[p]; }
+    for (int p = 0; p < 5; ++p) g.t0[p] = f.ph_t0[p];
+    g.Mpad = (g.M + 63) / 64 * 64;
+    long off = 0;
+    const int ngroups = (g.C + 15) / 16;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int T = g.t0[p + 1] - g.t0[p];
+        if (T == 0 || g.gw[p] < 24) return 0;
+        int oy0 = 1 << 30, ox0 = 1 << 30, oy1 = -(1 << 30), ox1 = -(1 << 30);
+        for (int t = g.t0[p]; t < g.t0[p + 1]; ++t) {
+            const int oy = (f.taps[t] & 0xff) - 64, ox = ((f.taps[t] >> 8) & 0xff) - 64;
+            oy0 = oy < oy0 ? oy : oy0; ox0 = ox < ox0 ? ox : ox0;
+            oy1 = oy > oy1 ? oy : oy1; ox1 = ox > ox1 ? ox : ox1;
+        }
+        g.oy0[p] = oy0; g.ox0[p] = ox0; g.span_y[p] = oy1 - oy0; g.span_x[p] = ox1 - ox0;
+        // tap group: all taps up to 9, otherwise the divisor-friendly group closest to 8 (7 for 7x7, 8 for 4x4)
+        int tg = T;
+        if (T > 9) {
+            tg = 8;
+            for (int cand = 9; cand >= 5; --cand)
+                if (T % cand == 0) { tg = cand; break; }
+        }
+        g.tg[p] = tg;
+        g.pack_off[p] = off;
+        off += (long)ngroups * T * 16 * g.Mpad;
+        for (int t = g.t0[p]; t < g.t0[p + 1]; ++t) {
+            const int oy = (f.taps[t] & 0xff) - 64, ox = ((f.taps[t] >> 8) & 0xff) - 64, wi = f.taps[t] >> 16;
+            g.taps[t] = (oy - oy0) | ((ox - ox0) << 8) | (wi << 16);
+        }
+    }
+    for (int p = g.nphase; p < 5; ++p) g.pack_off[p] = off;
+    g.plane_stride = (off + 7) & ~7L;
+    if (!sp_fits(g, 2, g.SI) && !sp_fits(g, 1, g.SI)) return 0;
+    return 1;
+}
+
+long split_pack_floats(const SplitGeom& g) { return g.plane_stride + 512; }   // 2 planes x 2 B = 4 B per element, + tail pad
+
+int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t s) {
+    const long total = g.pack_off[4];
+    if (total <= 0) return FAOCTASR_OK;
+    long blocks = (total + 255) / 256;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp), g, total);
+    return check_launch("split_pack");
+}
+
+template <int NI>
+static int sp_launch(const float* x, const float* wp, const float* bias, float* y, const SplitGeom& g, hipStream_t s) {
+    constexpr int TH = 4 * NI;
+    long mx = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        const long t = (long)g.N * ((g.gw[p] + 31) / 32) * ((g.gh[p] + TH - 1) / TH);
+        mx = t > mx ? t : mx;
+    }
+    if (mx == 0) return FAOCTASR_OK;
+    const int gy = (g.M + SP_MT - 1) / SP_MT;
+    const long blocks = mx * gy * g.nphase;
+    int ksplit = 1;
+    const int ngroups = (g.C + 15) / 16;
+    if (g.act == FAOCTASR_ACT_NONE && blocks < 256) {                   // one block per CU: fill the chip
+        ksplit = (int)(256 / blocks);
+        if (ksplit > ngroups / 2) ksplit = ngroups / 2;
+        ksplit = ksplit < 1 ? 1 : ksplit;
+    }
+    if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
+        return fail(FAOCTASR_EHIP, "memset y failed");
+    const size_t lds = sp_lds(g, NI, g.SI);
+    dim3 grid((unsigned)mx, gy, g.nphase * ksplit);
+    if (g.SI == 1) {
+        auto k = igemm_bf16x3_kernel<NI, 1>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+    } else {
+        auto k = igemm_bf16x3_kernel<NI, 2>;
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+    }
+    return check_launch("igemm_bf16x3");
+}
+
+int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s) {
+    g.act = act; g.slope = slope;
+    if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s);
+    return sp_launch<1>(x, wp, bias, y, g, s);
+}
+
+int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
+              int wpack_state, hipStream_t s) {
+    SplitGeom g;
+    if (!split_geom_from(f, g)) return 0;
+    if (wpack_state == 1) {
+        const int rc = launch_split_pack(w, wpack, g, s);
+        if (rc) return rc;
+    }
+    const int rc = launch_split(x, wpack, bias, y, g, act, slope, s);
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+long split_pack_floats_for(const IgemmGeom& f) {
+    SplitGeom g;
+    if (!split_geom_from(f, g)) return 0;
+    return split_pack_floats(g);
+}
+
+}  // namespace faoctasr

@@ -38,6 +38,12 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 
+// bf16x3 split-precision gather kernel (igemm_bf16x3.hip)
+struct SplitGeom;
+int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
+              int wpack_state, hipStream_t s);          // 1 launched, 0 not eligible, <0 error
+long split_pack_floats_for(const IgemmGeom& f);       // 0 when not eligible
+
 // single-output-channel 'same' stride-1 convolution on the VALU (conv_m1.hip)
 int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int KH, int KW, int pad,
                        int act, float slope, hipStream_t stream);

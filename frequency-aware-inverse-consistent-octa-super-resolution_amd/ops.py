@@ -40,6 +40,9 @@ import weakref
 #: bumped whenever weights change behind autograd's back (ParamArena.step updates them through raw pointers)
 weight_epoch = 0
 use_wpack = True
+#: convolution contraction precision: 0 = exact fp32 MFMA (default), 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate)
+conv_precision = 0
+PRECISIONS = {"f32": 0, "bf16x3": 2}
 _wpack_cache = {}
 
 
@@ -48,18 +51,18 @@ def invalidate_weight_cache():
     weight_epoch += 1
 
 
-def _wpack(w, kind, C, M, KH, KW, stride, pad):
+def _wpack(w, kind, C, M, KH, KW, stride, pad, size=None):
     """(buffer, state) for the C ABI: state 1 = pack now, 2 = buffer already holds these weights."""
     if not use_wpack:
         return None, 0
-    key = (id(w), kind, stride, pad)
+    key = (id(w), kind, stride, pad, conv_precision, size)
     ver = (w._version, weight_epoch, w.data_ptr(), tuple(w.shape))
     ent = _wpack_cache.get(key)
     if ent is None or ent[0]() is not w:
         if len(_wpack_cache) > 4096:
             for k in [k for k, v in _wpack_cache.items() if v[0]() is None]:
                 del _wpack_cache[k]
-        n = _lib.load().faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad)
+        n = _lib.load().faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad, conv_precision)
         if n <= 0:
             return None, 0
         ent = [weakref.ref(w), torch.empty(n, dtype=torch.float32, device=w.device), None]
@@ -92,9 +95,9 @@ class _Conv2d(Function):
             raise RuntimeError("Calculated padded input size per channel: (%d x %d). Kernel size: (%d x %d). "
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 0, C, M, KH, KW, stride, pad)
+        wp, wst = _wpack(w, 0, C, M, KH, KW, stride, pad, (IH, IW))
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
-             stream_ptr())
+             conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, reflect, act, slope)
@@ -116,14 +119,15 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, 0)
-                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst, st)
+                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, 0, (IH, IW))
+                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
+                     conv_precision, st)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
             else:
                 dx = torch.empty_like(x)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, pad)
-                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, st)
+                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, pad, (IH, IW))
+                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:
@@ -153,9 +157,9 @@ class _ConvTranspose2d(Function):
             raise _lib.KernelError("conv_transpose2d: input has %d channels, weight expects %d" % (C, Cw))
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 2, C, M, KH, KW, stride, pad)
+        wp, wst = _wpack(w, 2, C, M, KH, KW, stride, pad, (IH, IW))
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
-             ptr(wp), wst, stream_ptr())
+             ptr(wp), wst, conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, out_pad, act, slope)
@@ -176,8 +180,9 @@ class _ConvTranspose2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wp, wst = _wpack(ctx.w_ref, 3, C, M, KH, KW, stride, pad)
-            call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst, st)
+            wp, wst = _wpack(ctx.w_ref, 3, C, M, KH, KW, stride, pad, (IH, IW))
+            call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
+                 conv_precision, st)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:

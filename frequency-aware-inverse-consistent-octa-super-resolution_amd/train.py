@@ -76,7 +76,12 @@ class ParamArena:
 class TrainStep:
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
-                 process_group=None, distributed=None, init=True):
+                 process_group=None, distributed=None, init=True, precision="f32"):
+        """``precision``: "f32" = exact fp32 MFMA contraction (default); "bf16x3" = forward / input-gradient convolutions on
+        the bf16 matrix cores with hi/lo-split operands (fp32-parity: step-0 losses within ~1e-4; weight gradients stay fp32)."""
+        if precision not in ops.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(ops.PRECISIONS))
+        self.precision = precision
         dev = torch.device(device)
         made = netG_A2B is None
         self.netG_A2B = (netG_A2B or NetworkA2B()).to(dev)            # train.py:73-76
@@ -156,6 +161,7 @@ class TrainStep:
         """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats)."""
         B = real_A.shape[0]
         ones, zeros = self.targets(B)
+        ops.conv_precision = ops.PRECISIONS[self.precision]
         o = self.forward_generators(real_A, real_B)
         # (2) generators, train.py:218-239
         set_requires_grad([self.netD_A, self.netD_B], False)
@@ -177,6 +183,7 @@ class TrainStep:
         if self.distributed:
             self.opt_D.all_reduce(self.group)
         self.opt_D.step(1.0 / self.world)
+        ops.conv_precision = 0
         out = {k: v.detach() for k, v in L.items()}
         if sync:
             out = {k: float(v) for k, v in out.items()}

@@ -34,19 +34,24 @@ const char* faoctasr_last_error(void);
  * reflect!=0 folds nn.ReflectionPad2d(pad) (model.py:450,472) into the gather.          */
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
                         int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                        int reflect, int act, float slope, float* wpack, int wpack_state, faoctasr_stream_t stream);
+                        int reflect, int act, float slope, float* wpack, int wpack_state, int precision,
+                        faoctasr_stream_t stream);
 /* Packed-weight images for the LDS-patch kernel.  Every gather-type call (conv2d_fwd/dgrad,
  * conv_transpose2d_fwd/dgrad) takes an optional caller-owned buffer `wpack` of
  * faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad) floats (kind 0..3 in that order; C, M
  * as in the matching call) and `wpack_state`: 0 = none (flat im2col kernel), 1 = pack `w` into it
- * now, 2 = it already holds this `w` (valid until the weights change).                      */
-long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad);
+ * now, 2 = it already holds this `w` (valid until the weights change).
+ * `precision`: 0 = exact fp32 on v_mfma_f32_32x32x2_f32; 2 = "bf16x3": operands split hi/lo into bf16, three
+ * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (fp32-parity, ~5x the MFMA rate; needs a wpack buffer and
+ * C >= 16, width >= 24 -- other shapes silently use the fp32 kernels).  The packed image depends on `precision` and on
+ * whether the map is wide enough for the split kernel, so keep one buffer per (weights, precision, input size).  */
+long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad, int precision);
 /* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
  * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with
  * faoctasr_reflect_pad_bwd).                                                              */
 int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx,
                           int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                          float* wpack, int wpack_state, faoctasr_stream_t stream);
+                          float* wpack, int wpack_state, int precision, faoctasr_stream_t stream);
 /* aten::convolution_backward, weight gradient.  dw[M,C,KH,KW] is overwritten, or added to
  * when accumulate != 0 (the gradient arena is zeroed once per step instead).              */
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw,
@@ -56,11 +61,11 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw,
  * x[N,C,IH,IW], w[C,M,KH,KW], y[N,M,OH,OW], OH=(IH-1)*stride-2*pad+KH+out_pad.          */
 int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y,
                                   int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                                  int out_pad, int act, float slope, float* wpack, int wpack_state,
+                                  int out_pad, int act, float slope, float* wpack, int wpack_state, int precision,
                                   faoctasr_stream_t stream);
 int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx,
                                     int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                                    int out_pad, float* wpack, int wpack_state, faoctasr_stream_t stream);
+                                    int out_pad, float* wpack, int wpack_state, int precision, faoctasr_stream_t stream);
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw,
                                     int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                                     int out_pad, int accumulate, faoctasr_stream_t stream);

@@ -414,3 +414,54 @@ def test_losses_head_adamw(fa, O):
         arena.step()
     close(lin.weight.view(-1), pr, rtol=1e-6, atol=1e-7)
     assert lin.weight.data_ptr() == arena.flat.data_ptr()
+
+
+SPLIT_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] // c[6] >= 24]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv2d_bf16x3(fa, case):
+    """precision 2 ("bf16x3": operands split hi/lo into bf16, 3 bf16 MFMAs per product): forward and input gradient stay at
+    fp32-level accuracy (relative L2 error <= 3e-5 against the fp32 CPU result; plain fp32 MFMA gives ~1e-6)."""
+    N, C, H, W, M, k, s, p, reflect, bias, act = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(M, C, k, k, generator=g) * 0.05
+    b = torch.randn(M, generator=g) if bias else None
+    xr = x.clone().requires_grad_(True)
+    xin = F.pad(xr, (p, p, p, p), mode="reflect") if reflect else xr
+    ref = F.conv2d(xin, w, b, stride=s, padding=0 if reflect else p)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    fa.ops.conv_precision = 2
+    try:
+        xd = dev(x).requires_grad_(True)
+        out = fa.ops.conv2d(xd, dev(w), dev(b) if bias else None, s, p, reflect, None, 0.2)
+        out.backward(dev(cot))
+    finally:
+        fa.ops.conv_precision = 0
+    assert rel_l2(out, ref) < 3e-5
+    assert rel_l2(xd.grad, xr.grad) < 3e-5
+    # and it is NOT the plain-bf16 error level (~3e-3)
+    close(out, ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", [c for c in CONVT_CASES if c[1] >= 16 and c[3] >= 24])
+def test_conv_transpose2d_bf16x3(fa, case):
+    N, C, H, W, M, k, s, p, op, bias = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, M, k, k, generator=g) * 0.05
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, w, None, stride=s, padding=p, output_padding=op)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    fa.ops.conv_precision = 2
+    try:
+        xd = dev(x).requires_grad_(True)
+        out = fa.ops.conv_transpose2d(xd, dev(w), None, s, p, op)
+        out.backward(dev(cot))
+    finally:
+        fa.ops.conv_precision = 0
+    assert rel_l2(out, ref) < 3e-5
+    assert rel_l2(xd.grad, xr.grad) < 3e-5

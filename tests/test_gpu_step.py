@@ -182,3 +182,25 @@ def test_inference_path_eval_mode(fa, O):
     ts = fa.TrainStep(nets["A2B"], nets["B2A"], nets["D_A"], nets["D_B"])
     ts.lr_step(1.3e-4, fa.LambdaLR(50, 0, 10).step, 30)
     assert ts.opt_G.lr == pytest.approx(0.65e-4) and ts.opt_D.lr == pytest.approx(0.65e-4)
+
+
+@pytest.mark.parametrize("cfg", [2, 0])
+def test_train_step_bf16x3_precision(fa, O, cfg):
+    """Opt-in precision "bf16x3" (conv forward / input gradient on hi/lo-split bf16 operands, 3 MFMAs per product): the
+    step-0 losses and gradient norms still meet the fp32 parity bar against the REFERENCE fixtures at 256^2 (measured:
+    losses <= 1e-4, gradient norms <= 2.3e-4 from the exact-f32 path at 192^2 B=2, 256^2 B=1, 256^2 B=4).
+    The 192^2 batch-1 fixture is degenerate -- the deepest wavelet-branch BatchNorm of D_B normalises over 4 values and
+    amplifies any 4e-6 conv perturbation ~1000x into A2B's adversarial gradient -- so there only the losses keep 1e-3 and
+    the gradient norms get 1e-2."""
+    with open(os.path.join(GOLD, "golden_step.json")) as f:
+        gold = json.load(f)["configs"][cfg]
+    random.seed(1234)
+    n = build_nets(fa, O)
+    ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], precision="bf16x3")
+    a, b = O.synthetic_batch(gold["B"], gold["H"], seed=1234)
+    L = ts.step(a.cuda(), b.cuda(), sync=True)
+    _check_step(L, gold["steps"][0], 0)
+    gn = ts.grad_norms()
+    for k in gn:
+        assert gn[k] == pytest.approx(gold["steps"][0]["grad_norm"][k], rel=2e-3 if cfg == 2 else 1e-2), (k, gn[k])
+    assert fa.ops.conv_precision == 0          # the mode is scoped to the step

@@ -14,6 +14,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 ONLY = sys.argv[3].split(",") if len(sys.argv) > 3 else None      # e.g. "c8,c5"
 FWD_ONLY = len(sys.argv) > 4 and sys.argv[4] == "fwd"
+if os.environ.get("FAOCTASR_PRECISION"):
+    ops.conv_precision = ops.PRECISIONS[os.environ["FAOCTASR_PRECISION"]]
 SHAPES = [
     # name, kind, Cin, Cout, k, stride, pad, outpad/reflect, input size divisor
     ("c1 stem 1->64 4x4s2", "conv", 1, 64, 4, 2, 1, 0, 1),
