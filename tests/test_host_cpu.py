@@ -28,8 +28,9 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.declared_symbols()) == declared
     assert lib.faoctasr_version() >= 100
     assert lib.faoctasr_bn_workspace_floats(64) == 64 * 64 * 2
-    assert lib.faoctasr_conv_wpack_floats(0, 64, 64, 3, 3, 1, 1) > 64 * 64 * 9
-    assert lib.faoctasr_conv_wpack_floats(9, 64, 64, 3, 3, 1, 1) < 0          # unknown kind -> error code
+    assert lib.faoctasr_conv_wpack_floats(0, 64, 64, 3, 3, 1, 1, 0) > 64 * 64 * 9
+    assert lib.faoctasr_conv_wpack_floats(0, 64, 64, 3, 3, 1, 1, 2) >= lib.faoctasr_conv_wpack_floats(0, 64, 64, 3, 3, 1, 1, 0)
+    assert lib.faoctasr_conv_wpack_floats(9, 64, 64, 3, 3, 1, 1, 0) < 0       # unknown kind -> error code
     assert b"unknown kind" in lib.faoctasr_last_error()
 
 
