@@ -158,14 +158,16 @@ def main():
 
     roof = None
     extra = {}
-    if rank == 0 and not args.no_roofline:
-        timer = LaunchTimer(GATHER + WGRAD)
+    if not args.no_roofline:
+        # every rank runs these extra steps (they contain the gradient all-reduces); only rank 0 brackets its launches
+        timer = LaunchTimer(GATHER + WGRAD) if rank == 0 else None
         _lib.launch_timer = timer
         nroof = max(1, min(3, args.steps))
         for _ in range(nroof):
             ts.step(real_A, real_B)
         torch.cuda.synchronize()
         _lib.launch_timer = None
+    if rank == 0 and not args.no_roofline:
         ms, fl, cnt = timer.summary(GATHER)
         ach = fl / (ms * 1e-3) / 1e12
         traffic = None

@@ -18,6 +18,7 @@
 //     pipelined with hand-counted waits.
 #include "common.h"
 #include "igemm_geom.h"
+#include <cstdlib>
 
 namespace faoctasr {
 
@@ -37,6 +38,7 @@ struct SplitGeom {
     long pack_off[5];              // bf16 element offset of each phase inside a plane
     long plane_stride;             // bf16 elements between the hi and the lo plane
     int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
+    int ablate;                    // diagnostics only (FAOCTASR_SPLIT_ABLATE): 1 skip MFMAs, 2 skip patch loads, 4 skip patch store, 8 skip A DMA
 };
 
 __device__ __forceinline__ int reflect_idx_s(int i, int n) {
@@ -45,6 +47,20 @@ __device__ __forceinline__ int reflect_idx_s(int i, int n) {
 }
 
 __device__ __forceinline__ void ds_read_v8(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+
+// wait until only the OTHER fragment set's (MI + NI) * 2 reads are still outstanding; naming the registers keeps the consumer
+// MFMAs below the wait
+template <int MI, int NI>
+__device__ __forceinline__ void wait_keep_next(bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+    if constexpr (MI == 2 && NI == 2)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+    else if constexpr (MI == 2 && NI == 1)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]));
+    else if constexpr (MI == 1 && NI == 2)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]));
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing: fp32 W (arbitrary m / c strides, tap list) -> two bf16 planes in the LDS image order
@@ -71,14 +87,17 @@ __global__ void split_pack_kernel(const float* __restrict__ w, __bf16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NI, int SI>
-__global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
+// WM = 1: 4 waves, each 64 rows x NI pixel rows (MI = 2).  WM = 2: 8 waves, each 32 rows (MI = 1): two waves per SIMD from the
+// SAME block share its LDS image and hide each other's waits (the LDS footprint allows only one block per CU).
+template <int WM, int NI, int SI>
+__global__ __launch_bounds__(WM * 256) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
                                                            const int ksplit) {
-    constexpr int MI = 2, TH = 4 * NI;
+    constexpr int MI = 2 / WM, TH = 4 * NI, NT = WM * 256, NPI = SP_NPI / WM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
     const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
     const int tiles_x = (GW + 31) >> 5, tiles_y = (GH + TH - 1) / TH;
@@ -114,12 +133,12 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
 
     // patch items: item = h*PHW + pixel -> byte offset of channel 8h of that pixel inside the 16-channel group
     constexpr unsigned OOB = 0x80000000u;
-    unsigned poff[SP_NPI];
+    unsigned poff[NPI];
     const int nitems = 2 * PHW;
     const float invPW = 1.0f / (float)PW;
 #pragma unroll
-    for (int i = 0; i < SP_NPI; ++i) {
-        const int it = tid + 256 * i;
+    for (int i = 0; i < NPI; ++i) {
+        const int it = tid + NT * i;
         unsigned off = OOB;
         if (it < nitems) {
             const int h = it >= PHW ? 1 : 0;
@@ -135,7 +154,7 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
         }
         poff[i] = off;
     }
-    float pv[SP_NPI][8];
+    float pv[NPI][8];
     const unsigned cstep = 4u * (unsigned)chw;
 
     auto load_patch = [&](int grp) {
@@ -143,17 +162,18 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
         const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
                                                            (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < SP_NPI; ++i)
+        for (int i = 0; i < NPI; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
+                pv[i][j] = (g.ablate & 2) ? 1.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
     };
     auto store_patch = [&](int buf) {
+        if (g.ablate & 4) return;
         char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
         char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
 #pragma unroll
-        for (int i = 0; i < SP_NPI; ++i) {
-            const int it = tid + 256 * i;
+        for (int i = 0; i < NPI; ++i) {
+            const int it = tid + NT * i;
             if (it < nitems) {
                 bf16x8 hv, lv;
 #pragma unroll
@@ -170,11 +190,12 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
     };
     // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
     auto issue_A = [&](int grp, int tgi, int abuf) {
+        if (g.ablate & 8) return;
         const int tb = tgi * TG;
         int nt = T - tb;
         nt = nt < TG ? nt : TG;
         const int rows = nt * 2;                                        // (tap, h)
-        for (int r = wave; r < 2 * rows; r += 4) {
+        for (int r = wave; r < 2 * rows; r += WM * 4) {
             const int plane = r >= rows ? 1 : 0;
             const int rr = r - plane * rows;                            // tl*2 + h
             const __bf16* src = wp + plane * g.plane_stride + g.pack_off[ph] +
@@ -194,8 +215,8 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned a_lane = (unsigned)(lh * 64 + l31) * 16u;                                     // + tl*2048, + mi*512
-    const unsigned b_lane = (unsigned)((lh * PH + (wave * NI) * SI) * PW + l31 * SI) * 16u;       // + tap*16, + ni*SI*PW*16
+    const unsigned a_lane = (unsigned)(lh * 64 + wm * 32 + l31) * 16u;                           // + tl*2048, + mi*512
+    const unsigned b_lane = (unsigned)((lh * PH + (wn * NI) * SI) * PW + l31 * SI) * 16u;         // + tap*16, + ni*SI*PW*16
     const unsigned b_row = (unsigned)(SI * PW) * 16u;
 
     load_patch(g0);
@@ -232,6 +253,7 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
                 }
             };
             auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+                if (g.ablate & 1) return;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -245,22 +267,12 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
             rd(a0, b0, 0);
             for (int tl = 0; tl < nt; tl += 2) {
                 rd(a1, b1, tl + 1);                                     // runs past the slab on the last odd step: never used
-                if constexpr (NI == 2)
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
-                                 "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a0[0][0]), "+v"(a0[0][1]), "+v"(a0[1][0]), "+v"(a0[1][1]), "+v"(b0[0][0]),
-                                 "+v"(b0[0][1]));
+                wait_keep_next<MI, NI>(a0, b0);
                 mm(a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (tl + 1 >= nt) break;
                 rd(a0, b0, tl + 2);
-                if constexpr (NI == 2)
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]), "+v"(b1[0][0]),
-                                 "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]), "+v"(a1[1][1]), "+v"(b1[0][0]),
-                                 "+v"(b1[0][1]));
+                wait_keep_next<MI, NI>(a1, b1);
                 mm(a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
     }
 
     // epilogue (as igemm_patch.hip)
-    const int mrow0 = m0 + 4 * lh;
+    const int mrow0 = m0 + wm * 32 + 4 * lh;
     if (bias && ks == 0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void igemm_bf16x3_kernel(const float* __restri
     const int bo = tx * 32 + l31;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int ao = ty * TH + wave * NI + ni;
+        const int ao = ty * TH + wn * NI + ni;
         if (ao >= GH || bo >= GW) continue;
         float* yo = y + (long)n * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
 #pragma unroll
@@ -427,20 +439,33 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
         return fail(FAOCTASR_EHIP, "memset y failed");
     const size_t lds = sp_lds(g, NI, g.SI);
     dim3 grid((unsigned)mx, gy, g.nphase * ksplit);
-    if (g.SI == 1) {
-        auto k = igemm_bf16x3_kernel<NI, 1>;
+    static const int wm_sel = getenv("FAOCTASR_SPLIT_WM") ? atoi(getenv("FAOCTASR_SPLIT_WM")) : 2;
+    if (wm_sel == 1) {
+        if (g.SI == 1) {
+            auto k = igemm_bf16x3_kernel<1, NI, 1>;
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        } else {
+            auto k = igemm_bf16x3_kernel<1, NI, 2>;
+            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        }
+    } else if (g.SI == 1) {
+        auto k = igemm_bf16x3_kernel<2, NI, 1>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     } else {
-        auto k = igemm_bf16x3_kernel<NI, 2>;
+        auto k = igemm_bf16x3_kernel<2, NI, 2>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     }
     return check_launch("igemm_bf16x3");
 }
 
 int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s) {
     g.act = act; g.slope = slope;
+    static const int abl = getenv("FAOCTASR_SPLIT_ABLATE") ? atoi(getenv("FAOCTASR_SPLIT_ABLATE")) : 0;
+    g.ablate = abl;
     if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s);
     return sp_launch<1>(x, wp, bias, y, g, s);
 }

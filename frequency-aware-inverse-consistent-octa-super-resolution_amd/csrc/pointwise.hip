@@ -371,19 +371,29 @@ __global__ void fill_kernel(float* __restrict__ p, long n, float v) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-// per-channel sum over (N, HW): grid (C), block 256
+// per-channel sum over (N, HW): grid (S splits, C), block 256; partials combined with one atomic per block
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int C, int HW,
-                                                          int accumulate) {
+                                                          long per) {
     __shared__ float red[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.y;
     const long L = (long)N * HW;
+    long e0 = (long)blockIdx.x * per, e1 = e0 + per;
+    e1 = e1 < L ? e1 : L;
     float s = 0.f;
-    for (long e = threadIdx.x; e < L; e += 256) {
-        const long n = e / HW;
-        s += dy[((long)n * C + c) * HW + (e - n * HW)];
+    if ((HW & 3) == 0) {
+        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
+            const long n = e / HW;
+            const float4 v = *reinterpret_cast<const float4*>(dy + ((long)n * C + c) * HW + (e - n * HW));
+            s += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+            const long n = e / HW;
+            s += dy[((long)n * C + c) * HW + (e - n * HW)];
+        }
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+    if (threadIdx.x == 0) atomicAdd(db + c, s);
 }
 
 // fold of the gradient of ReflectionPad2d(p): each padded position maps back to one source pixel
@@ -737,7 +747,17 @@ int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream) {
 int faoctasr_channel_sum(const float* dy, float* db, int N, int C, int HW, int accumulate, faoctasr_stream_t stream) {
     if (!dy || !db) return fail(FAOCTASR_EINVAL, "channel_sum: null pointer");
     if (C <= 0) return FAOCTASR_OK;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, N, C, HW, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(db, 0, sizeof(float) * C, st) != hipSuccess) return fail(FAOCTASR_EHIP, "channel_sum: memset failed");
+    const long L = (long)N * HW;
+    long S = (1024 + C - 1) / C;                      // ~1024 blocks in total
+    const long maxs = (L + 4095) / 4096;
+    S = S < maxs ? S : maxs;
+    S = S < 1 ? 1 : S;
+    long per = (L + S - 1) / S;
+    per = (per + 3) & ~3L;
+    S = (L + per - 1) / per;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)S, C), dim3(256), 0, st, dy, db, N, C, HW, per);
     return check_launch("channel_sum");
 }
 
