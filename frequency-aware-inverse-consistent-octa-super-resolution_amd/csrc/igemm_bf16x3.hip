@@ -38,7 +38,6 @@ struct SplitGeom {
     long pack_off[5];              // bf16 element offset of each phase inside a plane
     long plane_stride;             // bf16 elements between the hi and the lo plane
     int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
-    int ablate;                    // diagnostics only (FAOCTASR_SPLIT_ABLATE): 1 skip MFMAs, 2 skip patch loads, 4 skip patch store, 8 skip A DMA
 };
 
 __device__ __forceinline__ int reflect_idx_s(int i, int n) {
@@ -87,26 +86,29 @@ __global__ void split_pack_kernel(const float* __restrict__ w, __bf16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// WM = 1: 4 waves, each 64 rows x NI pixel rows (MI = 2).  WM = 2: 8 waves, each 32 rows (MI = 1): two waves per SIMD from the
-// SAME block share its LDS image and hide each other's waits (the LDS footprint allows only one block per CU).
-template <int WM, int NI, int SI>
-__global__ __launch_bounds__(WM * 256) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
+// Wave-specialised 512-thread block: waves 0-3 are CONSUMERS (each 64 rows x NI pixel rows of 32: MI = 2 MFMA tiles high),
+// waves 4-7 are PRODUCERS (patch loads, hi/lo split, LDS stores, weight LDS-DMA for the next slab).  The LDS footprint
+// allows only one block per CU; without specialisation every wave is in the same phase at the same time and staging,
+// fragment reads and MFMAs simply add up (measured by ablation).  With it each SIMD hosts one consumer and one producer wave
+// whose pipes overlap.  The two roles run SEPARATE loops over the identical (tile, channel group, tap group) sequence and meet
+// at one s_barrier per slab, so the register allocation is max(producer, consumer), not their sum.  Blocks are persistent over
+// pixel tiles and the pipeline does not drain at tile boundaries.
+template <int NI, int SI>
+__global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
                                                            const int ksplit) {
-    constexpr int MI = 2 / WM, TH = 4 * NI, NT = WM * 256, NPI = SP_NPI / WM;
+    constexpr int MI = 2, TH = 4 * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;
+    const bool producer = wave >= 4;
+    const int wn = wave & 3, stid = tid & 255;
     const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
     const int tiles_x = (GW + 31) >> 5, tiles_y = (GH + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y;
-    const int bt = blockIdx.x;
-    if (bt >= g.N * tiles) return;
-    const int n = bt / tiles;
-    const int rt = bt - n * tiles;
-    const int ty = rt / tiles_x, tx = rt - ty * tiles_x;
+    const long total_tiles = (long)g.N * tiles;
+    if ((long)blockIdx.x >= total_tiles) return;
     const int t0 = g.t0[ph], T = g.t0[ph + 1] - t0, TG = g.tg[ph];
     const int ntg = (T + TG - 1) / TG;
     const int PH = (TH - 1) * SI + g.span_y[ph] + 1, PW = 31 * SI + g.span_x[ph] + 1, PHW = PH * PW;
@@ -121,91 +123,135 @@ __global__ __launch_bounds__(WM * 256) void igemm_bf16x3_kernel(const float* __r
     const unsigned a_bytes = (unsigned)TG * 2048u;                      // per plane per buffer: TG taps x 2 halves x 64 rows x 16 B
     const unsigned p_bytes = (unsigned)(2 * PHW) * 16u;                 // per plane per buffer
     const unsigned A_base = 0, P_base = 4u * a_bytes;
-    const int y_base = ty * TH * SI + g.oy0[ph], x_base = tx * 32 * SI + g.ox0[ph];
-    const float* xin = x + (long)n * g.C * chw;
+    auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {
+        n = (int)(tl / tiles);
+        const int rt = (int)(tl - (long)n * tiles);
+        ty = rt / tiles_x;
+        tx = rt - ty * tiles_x;
+    };
 
-    // tap offsets (in 16-byte pixel slots) in a lane table
-    int tapv = 0;
+    if (producer) {
+        // ================================================ PRODUCER ================================================
+        constexpr unsigned OOB = 0x80000000u;
+        unsigned poff[NPI];
+        const int nitems = 2 * PHW;
+        const float invPW = 1.0f / (float)PW;
+        const unsigned cstep = 4u * (unsigned)chw;
+        const float* xin = x;
+        float pv[NPI][8];
+        auto compute_poff = [&](long tl) {
+            int n, ty, tx;
+            tile_coords(tl, n, ty, tx);
+            const int y_base = ty * TH * SI + g.oy0[ph], x_base = tx * 32 * SI + g.ox0[ph];
+            xin = x + (long)n * g.C * chw;
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) {
+                const int it = stid + NT * i;                           // item = h*PHW + pixel
+                unsigned off = OOB;
+                if (it < nitems) {
+                    const int h = it >= PHW ? 1 : 0;
+                    const int p = it - h * PHW;
+                    const int py = (int)(((float)p + 0.5f) * invPW);
+                    const int px = p - py * PW;
+                    int iy = y_base + py, ix = x_base + px;
+                    if (g.reflect) {
+                        iy = reflect_idx_s(iy, IH);
+                        ix = reflect_idx_s(ix, IW);
+                    }
+                    if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = 4u * (unsigned)(8 * h * (int)chw + iy * IW + ix);
+                }
+                poff[i] = off;
+            }
+        };
+        auto load_patch = [&](int grp) {
+            const long bytes = (long)(g.C - grp * 16) * chw * 4;
+            const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
+                                                               (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NPI; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
+        };
+        auto store_patch = [&](int buf) {
+            char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
+            char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) {
+                const int it = stid + NT * i;
+                if (it < nitems) {
+                    bf16x8 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = pv[i][j];
+                        const __bf16 hb = (__bf16)v;
+                        hv[j] = hb;
+                        lv[j] = (__bf16)(v - (float)hb);
+                    }
+                    *reinterpret_cast<bf16x8*>(hi_p + it * 16) = hv;
+                    *reinterpret_cast<bf16x8*>(lo_p + it * 16) = lv;
+                }
+            }
+        };
+        // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
+        auto issue_A = [&](int grp, int tgi, int abuf) {
+            const int tb = tgi * TG;
+            int nt = T - tb;
+            nt = nt < TG ? nt : TG;
+            const int rows = nt * 2;                                    // (tap, h)
+            for (int r = wn; r < 2 * rows; r += 4) {
+                const int plane = r >= rows ? 1 : 0;
+                const int rr = r - plane * rows;                        // tl*2 + h
+                const __bf16* src = wp + plane * g.plane_stride + g.pack_off[ph] +
+                                    ((((long)grp * T + tb) * 2 + rr) * g.Mpad + m0) * 8 + lane * 8;
+                char* dst = smem + A_base + (abuf * 2 + plane) * a_bytes + rr * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        };
+
+        long tile = blockIdx.x;
+        compute_poff(tile);
+        load_patch(g0);
+        issue_A(g0, 0, 0);
+        store_patch(0);
+        __syncthreads();
+        int slab = 0, pcount = 0;
+        while (true) {
+            const long next_tile = tile + gridDim.x;
+            const bool has_next = next_tile < total_tiles;
+            for (int grp = g0; grp < g1; ++grp, ++pcount) {
+                const int pbuf = pcount & 1;
+                const bool last_grp = grp + 1 >= g1;
+                // prefetch the next patch (next channel group, or the first group of the NEXT tile) into registers
+                if (!last_grp) {
+                    load_patch(grp + 1);
+                } else if (has_next) {
+                    compute_poff(next_tile);
+                    load_patch(g0);
+                }
+                const bool more_patch = !last_grp || has_next;
+                for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
+                    const int abuf = slab & 1;
+                    if (tgi + 1 < ntg) issue_A(grp, tgi + 1, abuf ^ 1);
+                    else if (!last_grp) issue_A(grp + 1, 0, abuf ^ 1);
+                    else if (has_next) issue_A(g0, 0, abuf ^ 1);
+                    if (tgi == ntg - 1 && more_patch) store_patch(pbuf ^ 1);
+                    __syncthreads();                                     // LDS-DMA landed (vmcnt(0)), patch visible, consumers done
+                }
+            }
+            if (!has_next) break;
+            tile = next_tile;
+        }
+        return;
+    }
+
+    // ==================================================== CONSUMER ====================================================
+    int tapv = 0;                                                       // lane t: tap t's offset in 16-byte pixel slots
     if (lane < T) {
         const int tp = g.taps[t0 + lane];
         tapv = (tp & 0xff) * PW + ((tp >> 8) & 0xff);
     }
-
-    // patch items: item = h*PHW + pixel -> byte offset of channel 8h of that pixel inside the 16-channel group
-    constexpr unsigned OOB = 0x80000000u;
-    unsigned poff[NPI];
-    const int nitems = 2 * PHW;
-    const float invPW = 1.0f / (float)PW;
-#pragma unroll
-    for (int i = 0; i < NPI; ++i) {
-        const int it = tid + NT * i;
-        unsigned off = OOB;
-        if (it < nitems) {
-            const int h = it >= PHW ? 1 : 0;
-            const int p = it - h * PHW;
-            const int py = (int)(((float)p + 0.5f) * invPW);
-            const int px = p - py * PW;
-            int iy = y_base + py, ix = x_base + px;
-            if (g.reflect) {
-                iy = reflect_idx_s(iy, IH);
-                ix = reflect_idx_s(ix, IW);
-            }
-            if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = 4u * (unsigned)(8 * h * (int)chw + iy * IW + ix);
-        }
-        poff[i] = off;
-    }
-    float pv[NPI][8];
-    const unsigned cstep = 4u * (unsigned)chw;
-
-    auto load_patch = [&](int grp) {
-        const long bytes = (long)(g.C - grp * 16) * chw * 4;
-        const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
-                                                           (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NPI; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                pv[i][j] = (g.ablate & 2) ? 1.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
-    };
-    auto store_patch = [&](int buf) {
-        if (g.ablate & 4) return;
-        char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
-        char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
-#pragma unroll
-        for (int i = 0; i < NPI; ++i) {
-            const int it = tid + NT * i;
-            if (it < nitems) {
-                bf16x8 hv, lv;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = pv[i][j];
-                    const __bf16 hb = (__bf16)v;
-                    hv[j] = hb;
-                    lv[j] = (__bf16)(v - (float)hb);
-                }
-                *reinterpret_cast<bf16x8*>(hi_p + it * 16) = hv;
-                *reinterpret_cast<bf16x8*>(lo_p + it * 16) = lv;
-            }
-        }
-    };
-    // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
-    auto issue_A = [&](int grp, int tgi, int abuf) {
-        if (g.ablate & 8) return;
-        const int tb = tgi * TG;
-        int nt = T - tb;
-        nt = nt < TG ? nt : TG;
-        const int rows = nt * 2;                                        // (tap, h)
-        for (int r = wave; r < 2 * rows; r += WM * 4) {
-            const int plane = r >= rows ? 1 : 0;
-            const int rr = r - plane * rows;                            // tl*2 + h
-            const __bf16* src = wp + plane * g.plane_stride + g.pack_off[ph] +
-                                ((((long)grp * T + tb) * 2 + rr) * g.Mpad + m0) * 8 + lane * 8;
-            char* dst = smem + A_base + (abuf * 2 + plane) * a_bytes + rr * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -213,129 +259,136 @@ __global__ __launch_bounds__(WM * 256) void igemm_bf16x3_kernel(const float* __r
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned a_lane = (unsigned)(lh * 64 + wm * 32 + l31) * 16u;                           // + tl*2048, + mi*512
+    const unsigned a_lane = (unsigned)(lh * 64 + l31) * 16u;                                     // + tl*2048, + mi*512
     const unsigned b_lane = (unsigned)((lh * PH + (wn * NI) * SI) * PW + l31 * SI) * 16u;         // + tap*16, + ni*SI*PW*16
     const unsigned b_row = (unsigned)(SI * PW) * 16u;
 
-    load_patch(g0);
-    issue_A(g0, 0, 0);
-    store_patch(0);
-    __syncthreads();
-
-    int slab = 0;
-    for (int grp = g0; grp < g1; ++grp) {
-        const int pbuf = (grp - g0) & 1;
-        if (grp + 1 < g1) load_patch(grp + 1);                          // held in registers across this group's tap groups
-        for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
-            const int abuf = slab & 1;
-            if (tgi + 1 < ntg) issue_A(grp, tgi + 1, abuf ^ 1);
-            else if (grp + 1 < g1) issue_A(grp + 1, 0, abuf ^ 1);
-            const int tb = tgi * TG;
-            int nt = T - tb;
-            nt = nt < TG ? nt : TG;
-            const unsigned Ah = lds0 + A_base + (abuf * 2 + 0) * a_bytes + a_lane, Al = Ah + a_bytes;
-            const unsigned Ph = lds0 + P_base + (pbuf * 2 + 0) * p_bytes + b_lane, Pl = Ph + p_bytes;
-            bf16x8 a0[MI][2], b0[NI][2], a1[MI][2], b1[NI][2];
-            auto rd = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], int tl) {
-                const unsigned ao = (unsigned)tl * 2048u;
-                const unsigned bo = 16u * (unsigned)__builtin_amdgcn_readlane(tapv, (tb + tl) & 63);
+    long tile = blockIdx.x;
+    __syncthreads();                                                    // first patch + first weight slab staged by the producers
+    int slab = 0, pcount = 0;
+    while (true) {
+        const long next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < total_tiles;
+        for (int grp = g0; grp < g1; ++grp, ++pcount) {
+            const int pbuf = pcount & 1;
+            for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
+                const int abuf = slab & 1;
+                const int tb = tgi * TG;
+                int nt = T - tb;
+                nt = nt < TG ? nt : TG;
+                const unsigned Ah = lds0 + A_base + (abuf * 2 + 0) * a_bytes + a_lane, Al = Ah + a_bytes;
+                const unsigned Ph = lds0 + P_base + (pbuf * 2 + 0) * p_bytes + b_lane, Pl = Ph + p_bytes;
+                bf16x8 a0[MI][2], b0[NI][2], a1[MI][2], b1[NI][2];
+                auto rd = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], int tl) {
+                    const unsigned ao = (unsigned)tl * 2048u;
+                    const unsigned bo = 16u * (unsigned)__builtin_amdgcn_readlane(tapv, (tb + tl) & 63);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    ds_read_v8(a[mi][0], Ah + ao + mi * 512u);
-                    ds_read_v8(a[mi][1], Al + ao + mi * 512u);
-                }
+                    for (int mi = 0; mi < MI; ++mi) {
+                        ds_read_v8(a[mi][0], Ah + ao + mi * 512u);
+                        ds_read_v8(a[mi][1], Al + ao + mi * 512u);
+                    }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    ds_read_v8(b[ni][0], Ph + bo + ni * b_row);
-                    ds_read_v8(b[ni][1], Pl + bo + ni * b_row);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        ds_read_v8(b[ni][0], Ph + bo + ni * b_row);
+                        ds_read_v8(b[ni][1], Pl + bo + ni * b_row);
+                    }
+                };
+                auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);   // lo*hi
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);   // hi*lo
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);   // hi*hi
+                        }
+                };
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                rd(a0, b0, 0);
+                for (int tl = 0; tl < nt; tl += 2) {
+                    rd(a1, b1, tl + 1);                                 // runs past the slab on the last odd step: never used
+                    wait_keep_next<MI, NI>(a0, b0);
+                    mm(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tl + 1 >= nt) break;
+                    rd(a0, b0, tl + 2);
+                    wait_keep_next<MI, NI>(a1, b1);
+                    mm(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            };
-            auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
-                if (g.ablate & 1) return;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // retire run-ahead reads before LDS is rewritten
+                __syncthreads();
+            }
+        }
+        // ---- epilogue of this tile; the producers are already staging the next tile
+        {
+            int cn, cty, ctx;
+            tile_coords(tile, cn, cty, ctx);
+            const int mrow0 = m0 + 4 * lh;
+            if (bias && ks == 0) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);   // lo*hi
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);   // hi*lo
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);   // hi*hi
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
+                        const float bv = m < g.M ? bias[m] : 0.f;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][rr] += bv;
                     }
-            };
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            rd(a0, b0, 0);
-            for (int tl = 0; tl < nt; tl += 2) {
-                rd(a1, b1, tl + 1);                                     // runs past the slab on the last odd step: never used
-                wait_keep_next<MI, NI>(a0, b0);
-                mm(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tl + 1 >= nt) break;
-                rd(a0, b0, tl + 2);
-                wait_keep_next<MI, NI>(a1, b1);
-                mm(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // retire run-ahead reads before LDS is rewritten
-            if (tgi == ntg - 1 && grp + 1 < g1) store_patch(pbuf ^ 1);
-            __syncthreads();                                             // next A slab landed (vmcnt(0)), next patch visible
-        }
-    }
-
-    // epilogue (as igemm_patch.hip)
-    const int mrow0 = m0 + wm * 32 + 4 * lh;
-    if (bias && ks == 0) {
+            if (g.act == FAOCTASR_ACT_RELU) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
-                const float bv = m < g.M ? bias[m] : 0.f;
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][rr] += bv;
+                        for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = fmaxf(acc[mi][ni][rr], 0.f);
+            } else if (g.act == FAOCTASR_ACT_LRELU) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) {
+                            const float v = acc[mi][ni][rr];
+                            acc[mi][ni][rr] = v > 0.f ? v : v * g.slope;
+                        }
+            } else if (g.act == FAOCTASR_ACT_TANH) {
+                for (int mi = 0; mi < MI; ++mi)
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = tanhf(acc[mi][ni][rr]);
             }
-    }
-    if (g.act == FAOCTASR_ACT_RELU) {
+            const long ohw = (long)g.OH * g.OW;
+            const int bo = ctx * 32 + l31;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int ni = 0; ni < NI; ++ni) {
+                const int ao = cty * TH + wn * NI + ni;
+                if (ao < GH && bo < GW) {
+                    float* yo = y + (long)cn * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+                    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = fmaxf(acc[mi][ni][rr], 0.f);
-    } else if (g.act == FAOCTASR_ACT_LRELU) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const float v = acc[mi][ni][rr];
-                    acc[mi][ni][rr] = v > 0.f ? v : v * g.slope;
-                }
-    } else if (g.act == FAOCTASR_ACT_TANH) {
-        for (int mi = 0; mi < MI; ++mi)
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = tanhf(acc[mi][ni][rr]);
-    }
-    const long ohw = (long)g.OH * g.OW;
-    const int bo = tx * 32 + l31;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int ao = ty * TH + wn * NI + ni;
-        if (ao >= GH || bo >= GW) continue;
-        float* yo = y + (long)n * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
-                if (m < g.M) {
-                    if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
-                    else yo[(long)m * ohw] = acc[mi][ni][rr];
+                        for (int rr = 0; rr < 16; ++rr) {
+                            const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
+                            if (m < g.M) {
+                                if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
+                                else yo[(long)m * ohw] = acc[mi][ni][rr];
+                            }
+                        }
+                    }
                 }
             }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
+        if (!has_next) break;
+        tile = next_tile;
     }
 }
 
@@ -438,24 +491,18 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
         return fail(FAOCTASR_EHIP, "memset y failed");
     const size_t lds = sp_lds(g, NI, g.SI);
-    dim3 grid((unsigned)mx, gy, g.nphase * ksplit);
-    static const int wm_sel = getenv("FAOCTASR_SPLIT_WM") ? atoi(getenv("FAOCTASR_SPLIT_WM")) : 2;
-    if (wm_sel == 1) {
-        if (g.SI == 1) {
-            auto k = igemm_bf16x3_kernel<1, NI, 1>;
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
-        } else {
-            auto k = igemm_bf16x3_kernel<1, NI, 2>;
-            (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
-        }
-    } else if (g.SI == 1) {
-        auto k = igemm_bf16x3_kernel<2, NI, 1>;
+    // persistent blocks: one block per CU walks tiles bx, bx + gridDim.x, ... (the pipeline continues across tile boundaries)
+    long nbx = 256 / ((long)gy * g.nphase * ksplit);
+    nbx = nbx < 1 ? 1 : nbx;
+    static const int persist = getenv("FAOCTASR_SPLIT_PERSIST") ? atoi(getenv("FAOCTASR_SPLIT_PERSIST")) : 1;
+    if (!persist || nbx > mx) nbx = mx;
+    dim3 grid((unsigned)nbx, gy, g.nphase * ksplit);
+    if (g.SI == 1) {
+        auto k = igemm_bf16x3_kernel<NI, 1>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     } else {
-        auto k = igemm_bf16x3_kernel<2, NI, 2>;
+        auto k = igemm_bf16x3_kernel<NI, 2>;
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     }
@@ -464,8 +511,6 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
 
 int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s) {
     g.act = act; g.slope = slope;
-    static const int abl = getenv("FAOCTASR_SPLIT_ABLATE") ? atoi(getenv("FAOCTASR_SPLIT_ABLATE")) : 0;
-    g.ablate = abl;
     if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s);
     return sp_launch<1>(x, wp, bias, y, g, s);
 }
