@@ -450,18 +450,28 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
     return check_launch("igemm_patch");
 }
 
-// split K when the tile grid alone cannot fill the chip.  Residency is 2 blocks per CU (LDS budget) = 512 slots: a grid
-// slightly above a multiple of 512 runs a nearly empty extra round, so the split is sized to land just under one round.
+// split K when the tile grid alone cannot fill the chip or lands badly on it.  Residency is 2 blocks per CU (LDS budget) =
+// 512 slots, so a launch costs ceil(blocks * ks / 512) / ks rounds of full-K work: 128 blocks want ks = 4 (one full round of
+// quarter-K blocks), and 680 blocks (the 7x7 input gradient on its 134x134 padded grid) want ks = 3 (3.98 rounds of thirds =
+// 1.33 instead of 2).  Each split adds one atomic pass over the output, priced as ~30 K-steps per split relative to the K depth.
 static int pick_ksplit(const PatchGeom& g, long blocks, int act) {
-    if (act != FAOCTASR_ACT_NONE || blocks > 256) return 1;
-    int minchunks = 1 << 30;
+    if (act != FAOCTASR_ACT_NONE || blocks <= 0) return 1;
+    int minchunks = 1 << 30, kdepth = 1 << 30;
     for (int p = 0; p < g.nphase; ++p) {
         const int nc = (g.C + g.kc[p] - 1) / g.kc[p];
         minchunks = nc < minchunks ? nc : minchunks;
+        const int kd = g.C * (g.t0[p + 1] - g.t0[p]);
+        kdepth = kd < kdepth ? kd : kdepth;
     }
-    int ks = (int)(512 / blocks);
-    if (ks > minchunks / 2) ks = minchunks / 2;
-    return ks < 1 ? 1 : ks;
+    int best = 1;
+    double best_cost = (double)((blocks + 511) / 512);
+    const int ks_max = minchunks / 2 < 8 ? minchunks / 2 : 8;
+    for (int ks = 2; ks <= ks_max; ++ks) {
+        const double rounds = (double)((blocks * ks + 511) / 512) / ks;
+        const double cost = rounds * (1.0 + 30.0 * ks / kdepth);
+        if (cost < best_cost * 0.97) { best = ks; best_cost = cost; }
+    }
+    return best;
 }
 
 // returns 1 when the patch kernel was launched, 0 when the shape is left to the flat kernel, <0 on error
@@ -474,7 +484,7 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
     int rc;
     if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
         rc = launch_cfg<2, 2, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 2, 2>(g), act), s);
-    } else if (g.M <= 64 && patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 256) {
+    } else if (patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 256) {
         rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);
     } else if (patch_fits<2, 2, 1, 2>(g, g.SI)) {
         rc = launch_cfg<2, 2, 1, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 1, 2>(g), act), s);
