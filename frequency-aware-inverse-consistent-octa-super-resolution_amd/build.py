@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "wgrad_patch.hip", "conv_m1.hip", "pointwise.hip", "sgemm.hip", "ssim.hip"]
+SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "wgrad_patch.hip", "conv_m1.hip", "pointwise.hip", "sgemm.hip", "ssim.hip"]
 LIB = os.path.join(HERE, "libfaoctasr.so")
 
 

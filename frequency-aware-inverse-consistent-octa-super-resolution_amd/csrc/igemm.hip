@@ -405,12 +405,17 @@ static int launch_wgrad(const float* x, const float* dy, float* dw, IgemmGeom& g
 static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || !b || !c; }
 
 // wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
-// precision: 0 = exact f32 MFMA; 2 = bf16x3 split operands on the bf16 MFMA where the layer shape allows it
+// precision: 0 = f32 MFMA, Winograd F(2x2,3x3) for the dense stride-1 3x3 gathers and direct implicit GEMM elsewhere;
+//            1 = f32 MFMA, direct implicit GEMM only; 2 = bf16x3 split operands on the bf16 MFMA where the layer shape allows it
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
                       int wpack_state, int precision, hipStream_t s) {
-    if (precision != 0 && precision != 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 2 = bf16x3)", precision);
+    if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     if (wpack && wpack_state && precision == 2) {
         const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+    }
+    if (wpack && wpack_state && precision == 0) {
+        const int rc = wino_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
         if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
     }
     if (wpack && wpack_state) {
@@ -433,6 +438,10 @@ static long wpack_floats(IgemmGeom& g, int precision) {
     long n = patch_pack_floats(pg);
     if (precision == 2) {
         const long m = split_pack_floats_for(g);
+        n = m > n ? m : n;
+    }
+    if (precision == 0) {
+        const long m = wino_pack_floats_for(g);
         n = m > n ? m : n;
     }
     return n;

@@ -44,6 +44,11 @@ int split_try(const IgemmGeom& f, const float* x, const float* w, const float* b
               int wpack_state, hipStream_t s);          // 1 launched, 0 not eligible, <0 error
 long split_pack_floats_for(const IgemmGeom& f);       // 0 when not eligible
 
+// Winograd F(2x2,3x3) fp32 kernel for dense stride-1 3x3 gathers (igemm_wino.hip)
+int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
+             int wpack_state, hipStream_t s);           // 1 launched, 0 not eligible, <0 error
+long wino_pack_floats_for(const IgemmGeom& f);        // 0 when not eligible
+
 // single-output-channel 'same' stride-1 convolution on the VALU (conv_m1.hip)
 int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int KH, int KW, int pad,
                        int act, float slope, hipStream_t stream);

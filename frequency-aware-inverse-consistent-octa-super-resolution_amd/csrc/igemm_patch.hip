@@ -482,7 +482,10 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
         if (g.gw[p] < 24 || g.t0[p + 1] - g.t0[p] == 0) return 0;       // narrow maps: the flat kernel wastes fewer lanes
     // config A: 128 x (4x32); B: 64 x (8x32); C: 64 x (4x32)
     int rc;
-    if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
+    static const int force = getenv("FAOCTASR_PATCH_CFG") ? atoi(getenv("FAOCTASR_PATCH_CFG")) : 0;
+    if (force == 2 && patch_fits<1, 4, 2, 2>(g, g.SI)) {
+        rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);
+    } else if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
         rc = launch_cfg<2, 2, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 2, 2>(g), act), s);
     } else if (patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 256) {
         rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);

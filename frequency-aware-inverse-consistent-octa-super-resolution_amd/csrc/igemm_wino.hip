@@ -1,0 +1,425 @@
+// Winograd F(2x2, 3x3) convolution for gfx950, fp32 throughout (f32 MFMA v_mfma_f32_16x16x4_f32).
+//
+// Serves every stride-1 3x3 gather of the path -- forward of the 3x3 convolutions (model.py:242-258, 403-421, 483-506) and
+// their input gradients (a 3x3 correlation with the transposed, rotated filter) -- which is 52 % of the convolution time of
+// the benchmark step.  Y = A^T [ (G g G^T) .* (B^T d B) ] A turns 36 multiply-adds per 2x2 output tile and channel pair into
+// 16, i.e. 2.25x less MFMA work; all arithmetic stays fp32 (the transforms are exact +/- and *0.5, rounding grows by a small
+// constant: per-layer error ~1e-6 relative, against the 1e-3 parity bar).
+//
+// Block = 64 output channels x 32 Winograd tiles (2 tile rows x 16 tile columns = 4 x 32 output pixels), 512 threads:
+//   waves 4-7 PRODUCERS: one (tile, channel) pair per thread and 8-channel chunk -- 16 buffer loads (zero padding = offset
+//             past the descriptor's range), B^T d B in registers, 16 scattered LDS stores into V[xi][k][tile]; plus the
+//             LDS-DMA of the chunk's transformed-weight slab U[xi][k][m] (32 KiB contiguous in the packed image);
+//   waves 0-3 CONSUMERS: wave w owns output channels 16w..16w+15 x all 32 tiles x all 16 Winograd positions xi:
+//             32 accumulator tiles of 16x16 (128 registers).  Because one lane holds all 16 xi of its (channel, tile)
+//             elements, the output transform A^T M A, bias and activation run in registers and results go straight to HBM.
+// Roles run separate loops over the same (tile, chunk) sequence and meet at one barrier per chunk; blocks are persistent
+// over pixel tiles so the pipeline does not drain between tiles.
+//
+// LDS operand order: within a chunk the 8 channels are split as c = k + 4 j (k = 0..3 is the MFMA's K index = lane >> 4,
+// j = 0, 1 the two MFMAs of the chunk); element (xi, k, row, j) sits at ((xi * 4 + k) * ROWS + row) * 2 + j, so one
+// ds_read_b64 per lane fetches the operands of both MFMAs and every 8 lanes read 64 contiguous bytes (conflict-free).
+#include <type_traits>
+
+#include "common.h"
+#include "igemm_geom.h"
+
+namespace faoctasr {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+constexpr int WN_MT = 64;                 // output channels per block
+constexpr int WN_KC = 8;                  // channels per chunk
+constexpr int WN_U_FLOATS = 16 * WN_KC * WN_MT;      // 8192 floats = 32 KiB per chunk
+constexpr int WN_V_FLOATS = 16 * WN_KC * 32;         // 4096 floats = 16 KiB per chunk
+constexpr unsigned WN_SENT = 0x40000000u;            // offset sentinel: beyond any admitted per-image extent
+
+struct WinoGeom {
+    int N, C, IH, IW, M, OH, OW, act;
+    float slope;
+    int oy0, ox0;                  // input offset of filter tap (0, 0) relative to the output pixel
+    int widx[9];                   // weight index of filter tap (i, j)
+    long wsm, wsc;
+    int nchunks, mtiles;
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// U = G g G^T, written in the order the kernel's LDS-DMA wants: [mtile][chunk][xi][k][m][j], c = chunk*8 + k + 4j
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, const WinoGeom g, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long li = i;
+        const int j = (int)(li & 1); li >>= 1;
+        const int ml = (int)(li & 63); li >>= 6;
+        const int k = (int)(li & 3); li >>= 2;
+        const int xi = (int)(li & 15); li >>= 4;
+        const int ch = (int)(li % g.nchunks);
+        const int mt = (int)(li / g.nchunks);
+        const int m = mt * WN_MT + ml, c = ch * WN_KC + k + 4 * j;
+        float v = 0.f;
+        if (m < g.M && c < g.C) {
+            const float* wp = w + (long)m * g.wsm + (long)c * g.wsc;
+            float gg[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) gg[a][b] = wp[g.widx[a * 3 + b]];
+            const int a = xi >> 2, b = xi & 3;
+            // row a of G applied to the columns, then row b of G applied to the result
+            float t[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                t[q] = a == 0 ? gg[0][q] : a == 3 ? gg[2][q] : a == 1 ? 0.5f * (gg[0][q] + gg[1][q] + gg[2][q]) : 0.5f * (gg[0][q] - gg[1][q] + gg[2][q]);
+            }
+            v = b == 0 ? t[0] : b == 3 ? t[2] : b == 1 ? 0.5f * (t[0] + t[1] + t[2]) : 0.5f * (t[0] - t[1] + t[2]);
+        }
+        up[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict__ x, const float* __restrict__ up,
+                                                         const float* __restrict__ bias, float* __restrict__ y, const WinoGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const U_lds = reinterpret_cast<float*>(smem);               // 3 x WN_U_FLOATS (weights are fetched two slabs ahead)
+    float* const V_lds = U_lds + 3 * WN_U_FLOATS;                      // 2 x WN_V_FLOATS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int wn = wave & 3;
+    const int tiles_x = (g.OW + 31) >> 5, tiles_y = (g.OH + 3) >> 2;
+    const int tiles = tiles_x * tiles_y;
+    const long total_tiles = (long)g.N * tiles;
+    if ((long)blockIdx.x >= total_tiles) return;
+    const int mt = blockIdx.y;
+    const int nchunks = g.nchunks;
+    const long chw = (long)g.IH * g.IW;
+    auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {
+        n = (int)(tl / tiles);
+        const int rt = (int)(tl - (long)n * tiles);
+        ty = rt / tiles_x;
+        tx = rt - ty * tiles_x;
+    };
+
+    if (producer) {
+        // ================================================ PRODUCER ================================================
+        // Slab q = (tile q / nchunks, chunk q % nchunks) of this block's tile sequence; the consumers work on slab q between
+        // barrier(q-1) and barrier(q).  In that interval the producers (1) transform the patch of slab q+1 (loaded one slab
+        // ago) into the other V buffer, (2) issue the weight DMA of slab q+2 into the third U buffer, (3) issue the patch loads
+        // of slab q+2.  (2) and (3) stay in flight across the barrier: vmcnt(24) retires everything older than this step's 8
+        // DMA rows and 16 loads.
+        const int stid = tid & 255;
+        const int tile = stid & 31, cl = stid >> 5;                     // (tile, local channel 0..7)
+        const int tr = tile >> 4, tc = tile & 15;
+        const int kk = cl & 3, jj = cl >> 2;
+        float* const vdst0 = V_lds + ((kk * 32 + tile) * 2 + jj);       // + xi*256 floats, + buf*WN_V_FLOATS
+        const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + lane * 4;
+        unsigned rowoff[4], coloff[4];
+        float d[4][4];
+        __amdgpu_buffer_rsrc_t srd;
+        auto set_tile = [&](long tl) {
+            int n, ty, tx;
+            tile_coords(tl, n, ty, tx);
+            const int iy0 = 4 * ty + 2 * tr + g.oy0, ix0 = 32 * tx + 2 * tc + g.ox0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rowoff[r] = (unsigned)(iy0 + r) < (unsigned)g.IH ? 4u * (unsigned)((iy0 + r) * g.IW) : WN_SENT;
+                coloff[r] = (unsigned)(ix0 + r) < (unsigned)g.IW ? 4u * (unsigned)(ix0 + r) : WN_SENT;
+            }
+            srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * g.C * chw), 0, (int)((long)g.C * chw * 4), 0x00020000);
+        };
+        auto load_d = [&](int ch) {
+            const unsigned coff = 4u * (unsigned)((ch * WN_KC + cl) * (int)chw);       // past the range for c >= C: reads 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    d[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, coff + rowoff[r] + coloff[c], 0, 0));
+        };
+        auto store_v = [&](int buf) {
+            float* vd = vdst0 + buf * WN_V_FLOATS;
+            float t[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                                // B^T d
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                // (.) B
+                vd[(r * 4 + 0) * 256] = t[r][0] - t[r][2];
+                vd[(r * 4 + 1) * 256] = t[r][1] + t[r][2];
+                vd[(r * 4 + 2) * 256] = t[r][2] - t[r][1];
+                vd[(r * 4 + 3) * 256] = t[r][1] - t[r][3];
+            }
+        };
+        auto issue_U = [&](int ch, int buf) {
+            const float* src = usrc + (long)ch * WN_U_FLOATS;
+            float* dst = U_lds + buf * WN_U_FLOATS;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wn + 4 * i;                               // 1 KiB row of the 32 KiB slab
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 256),
+                                                 (__attribute__((address_space(3))) void*)(dst + r * 256), 16, 0, 0);
+            }
+        };
+        auto barrier = [&](bool ahead) {
+            if (ahead) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        const long my_tiles = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+        const long q_total = my_tiles * nchunks;
+        long tl_load = blockIdx.x;                                      // tile / chunk of the look-ahead cursor
+        int ch_load = 0, ubuf = 1;
+        auto advance = [&]() {                                          // weights + patch loads of the next slab in sequence
+            if (++ch_load == nchunks) {
+                ch_load = 0;
+                tl_load += gridDim.x;
+                set_tile(tl_load);
+            }
+            issue_U(ch_load, ubuf);
+            ubuf = ubuf == 2 ? 0 : ubuf + 1;
+            load_d(ch_load);
+        };
+        set_tile(tl_load);
+        issue_U(0, 0);
+        load_d(0);
+        store_v(0);                                                      // slab 0 complete in LDS after the barrier
+        if (q_total > 1) advance();                                      // slab 1: weights -> U[1], patch -> registers
+        barrier(q_total > 1);
+        for (long q = 0; q < q_total; ++q) {
+            if (q + 1 < q_total) store_v((int)((q + 1) & 1));
+            const bool more = q + 2 < q_total;
+            if (more) advance();
+            barrier(more);
+        }
+        return;
+    }
+
+    // ==================================================== CONSUMER ====================================================
+    f32x4w acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[xi][nt][r] = 0.f;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ua0 = lds0 + (unsigned)((lk * 64 + 16 * wn + l15) * 8);                               // + xi*2048 + buf*32768
+    const unsigned vb0 = lds0 + 3u * WN_U_FLOATS * 4u + (unsigned)((lk * 32 + l15) * 8);                  // + xi*1024 + nt*128 + buf*16384
+    const long ohw = (long)g.OH * g.OW;
+    const bool pair_ok = (g.OW & 1) == 0;
+
+    // Finished tiles are not stored at once: the 16 (float2) results of a lane wait in registers and leave two per slab
+    // during the next tile's reduction.  All blocks of the persistent grid run in step, so storing at the tile boundary would
+    // hit HBM in bursts with every MFMA pipe idle behind a full store queue (measured: 19 % of the kernel).
+    f32x2 pend[16];                                                     // item j = (nt = j >> 3, r = (j >> 1) & 3, a2 = j & 1)
+    float* pbase = y;                                                   // &y[n][m_base][4 ty][ox] of the pending tile
+    unsigned pmask = 0;                                                  // bit j: item j is inside the tensor
+    bool px1 = false;                                                    // second pixel of the pair inside the row (odd OW)
+    auto st = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int nt = j >> 3, r = (j >> 1) & 3, a2 = j & 1;
+        if (pmask & (1u << j)) {
+            float* p = pbase + r * ohw + (long)(2 * nt + a2) * g.OW;
+            if (pair_ok) {
+                *reinterpret_cast<f32x2*>(p) = pend[j];
+            } else {
+                p[0] = pend[j][0];
+                if (px1) p[1] = pend[j][1];
+            }
+        }
+    };
+    auto flush_from = [&](int k) {                                       // items k .. 15
+        switch (k) {
+            case 0: st(std::integral_constant<int, 0>{}); [[fallthrough]];
+            case 1: st(std::integral_constant<int, 1>{}); [[fallthrough]];
+            case 2: st(std::integral_constant<int, 2>{}); [[fallthrough]];
+            case 3: st(std::integral_constant<int, 3>{}); [[fallthrough]];
+            case 4: st(std::integral_constant<int, 4>{}); [[fallthrough]];
+            case 5: st(std::integral_constant<int, 5>{}); [[fallthrough]];
+            case 6: st(std::integral_constant<int, 6>{}); [[fallthrough]];
+            case 7: st(std::integral_constant<int, 7>{}); [[fallthrough]];
+            case 8: st(std::integral_constant<int, 8>{}); [[fallthrough]];
+            case 9: st(std::integral_constant<int, 9>{}); [[fallthrough]];
+            case 10: st(std::integral_constant<int, 10>{}); [[fallthrough]];
+            case 11: st(std::integral_constant<int, 11>{}); [[fallthrough]];
+            case 12: st(std::integral_constant<int, 12>{}); [[fallthrough]];
+            case 13: st(std::integral_constant<int, 13>{}); [[fallthrough]];
+            case 14: st(std::integral_constant<int, 14>{}); [[fallthrough]];
+            case 15: st(std::integral_constant<int, 15>{}); [[fallthrough]];
+            default: break;
+        }
+    };
+    auto st_pair = [&](int ch) {                                         // items 2 ch, 2 ch + 1 (ch < 8)
+        switch (ch) {
+            case 0: st(std::integral_constant<int, 0>{}); st(std::integral_constant<int, 1>{}); break;
+            case 1: st(std::integral_constant<int, 2>{}); st(std::integral_constant<int, 3>{}); break;
+            case 2: st(std::integral_constant<int, 4>{}); st(std::integral_constant<int, 5>{}); break;
+            case 3: st(std::integral_constant<int, 6>{}); st(std::integral_constant<int, 7>{}); break;
+            case 4: st(std::integral_constant<int, 8>{}); st(std::integral_constant<int, 9>{}); break;
+            case 5: st(std::integral_constant<int, 10>{}); st(std::integral_constant<int, 11>{}); break;
+            case 6: st(std::integral_constant<int, 12>{}); st(std::integral_constant<int, 13>{}); break;
+            case 7: st(std::integral_constant<int, 14>{}); st(std::integral_constant<int, 15>{}); break;
+            default: break;
+        }
+    };
+
+    long tl = blockIdx.x;
+    asm volatile("s_barrier" ::: "memory");
+    int slab = 0, ub = 0;
+    while (true) {
+        const long next_tile = tl + gridDim.x;
+        const bool has_next = next_tile < total_tiles;
+        for (int ch = 0; ch < nchunks; ++ch, ++slab) {
+            const unsigned ua = ua0 + (unsigned)ub * (WN_U_FLOATS * 4u), vb = vb0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u);
+            ub = ub == 2 ? 0 : ub + 1;
+            if (pmask) st_pair(ch);
+            // fragment reads run two xi steps (8 MFMAs = 256 cycles) ahead of their use
+            f32x2 a[3], b0[3], b1[3];
+            asm volatile("ds_read_b64 %0, %1" : "=v"(a[0]) : "v"(ua));
+            asm volatile("ds_read_b64 %0, %1" : "=v"(b0[0]) : "v"(vb));
+            asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(b1[0]) : "v"(vb));
+            asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(a[1]) : "v"(ua));
+            asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(b0[1]) : "v"(vb));
+            asm volatile("ds_read_b64 %0, %1 offset:1152" : "=v"(b1[1]) : "v"(vb));
+            static_for<0, 16>([&](auto ic) {
+                constexpr int xi = decltype(ic)::value;
+                constexpr int cur = xi % 3, nx2 = (xi + 2) % 3;
+                if constexpr (xi + 2 < 16) {
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[nx2]) : "v"(ua), "n"((xi + 2) * 2048));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b0[nx2]) : "v"(vb), "n"((xi + 2) * 1024));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b1[nx2]) : "v"(vb), "n"((xi + 2) * 1024 + 128));
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
+                } else if constexpr (xi + 1 < 16) {
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
+                }
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][0], b0[cur][0], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][0], b1[cur][0], acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][1], b0[cur][1], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][1], b1[cur][1], acc[xi][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_barrier" ::: "memory");                      // all LDS reads of this slab retired (lgkmcnt(0) above)
+        }
+        // ---- output transform of this tile into the pending registers (the producers are already staging the next tile)
+        {
+            if (pmask && nchunks < 8) flush_from(2 * nchunks);           // short reductions: what the slabs did not get to
+            int n, ty, tx;
+            tile_coords(tl, n, ty, tx);
+            const int ox = 32 * tx + 2 * l15;
+            const int m_base = mt * WN_MT + 16 * wn + 4 * lk;
+            pbase = y + ((long)n * g.M + m_base) * ohw + (long)(4 * ty) * g.OW + ox;
+            px1 = ox + 1 < g.OW;
+            pmask = 0;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s0[4], s1[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        s0[b] = acc[0 + b][nt][r] + acc[4 + b][nt][r] + acc[8 + b][nt][r];
+                        s1[b] = acc[4 + b][nt][r] - acc[8 + b][nt][r] - acc[12 + b][nt][r];
+                    }
+                    const int m = m_base + r;
+                    const float bv = (bias && m < g.M) ? bias[m] : 0.f;
+                    pend[nt * 8 + r * 2 + 0] = f32x2{act_apply(s0[0] + s0[1] + s0[2] + bv, g.act, g.slope), act_apply(s0[1] - s0[2] - s0[3] + bv, g.act, g.slope)};
+                    pend[nt * 8 + r * 2 + 1] = f32x2{act_apply(s1[0] + s1[1] + s1[2] + bv, g.act, g.slope), act_apply(s1[1] - s1[2] - s1[3] + bv, g.act, g.slope)};
+                    if (m < g.M && ox < g.OW) {
+                        if (4 * ty + 2 * nt < g.OH) pmask |= 1u << (nt * 8 + r * 2);
+                        if (4 * ty + 2 * nt + 1 < g.OH) pmask |= 1u << (nt * 8 + r * 2 + 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[xi][nt][r] = 0.f;
+        }
+        if (!has_next) break;
+        tl = next_tile;
+    }
+    flush_from(0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+// 1 when the gather is a dense stride-1 3x3 correlation this kernel serves
+static int wino_geom_from(const IgemmGeom& f, WinoGeom& g) {
+    if (f.nphase != 1 || f.SI != 1 || f.SO != 1 || f.reflect || f.ph_t0[1] - f.ph_t0[0] != 9) return 0;
+    if (f.C < 16 || f.M < 16 || f.ph_gw[0] < 24 || f.ph_gh[0] < 2) return 0;
+    if ((long)f.C * f.IH * f.IW * 4 >= (long)WN_SENT) return 0;
+    g = WinoGeom{};
+    int oy0 = 1 << 30, ox0 = 1 << 30;
+    for (int t = 0; t < 9; ++t) {
+        const int oy = (f.taps[t] & 0xff) - 64, ox = ((f.taps[t] >> 8) & 0xff) - 64;
+        oy0 = oy < oy0 ? oy : oy0;
+        ox0 = ox < ox0 ? ox : ox0;
+    }
+    int seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int i = (f.taps[t] & 0xff) - 64 - oy0, j = ((f.taps[t] >> 8) & 0xff) - 64 - ox0;
+        if (i < 0 || i > 2 || j < 0 || j > 2) return 0;
+        g.widx[i * 3 + j] = f.taps[t] >> 16;
+        seen |= 1 << (i * 3 + j);
+    }
+    if (seen != 0x1ff) return 0;
+    g.N = f.N; g.C = f.C; g.IH = f.IH; g.IW = f.IW; g.M = f.M; g.OH = f.OH; g.OW = f.OW;
+    g.oy0 = oy0; g.ox0 = ox0; g.wsm = f.wsm; g.wsc = f.wsc;
+    g.nchunks = (g.C + WN_KC - 1) / WN_KC;
+    g.mtiles = (g.M + WN_MT - 1) / WN_MT;
+    return 1;
+}
+
+static long wino_tiles(const WinoGeom& g) { return (long)g.N * ((g.OW + 31) / 32) * ((g.OH + 3) / 4); }
+
+// the persistent grid wants at least half a chip of blocks; smaller problems stay on the split-K patch kernel
+static bool wino_worth(const WinoGeom& g) { return wino_tiles(g) * g.mtiles >= 128; }
+
+long wino_pack_floats_for(const IgemmGeom& f) {
+    WinoGeom g;
+    if (!wino_geom_from(f, g)) return 0;              // sizing is asked on a nominal grid: shape eligibility only
+    return (long)g.mtiles * g.nchunks * WN_U_FLOATS + 256;
+}
+
+int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
+             int wpack_state, hipStream_t s) {
+    static const int enabled = getenv("FAOCTASR_WINOGRAD") ? atoi(getenv("FAOCTASR_WINOGRAD")) : 1;
+    WinoGeom g;
+    if (!enabled || !wino_geom_from(f, g) || !wino_worth(g)) return 0;
+    g.act = act; g.slope = slope;
+    if (wpack_state == 1) {
+        const long total = (long)g.mtiles * g.nchunks * WN_U_FLOATS;
+        long blocks = (total + 255) / 256;
+        blocks = blocks > 4096 ? 4096 : blocks;
+        hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, wpack, g, total);
+        const int rc = check_launch("wino_pack");
+        if (rc) return rc;
+    }
+    const long tiles = wino_tiles(g);
+    long nbx = 256 / g.mtiles;
+    nbx = nbx < 1 ? 1 : nbx;
+    nbx = nbx > tiles ? tiles : nbx;
+    const size_t lds = (3 * (size_t)WN_U_FLOATS + 2 * (size_t)WN_V_FLOATS) * 4;
+    auto k = igemm_wino_kernel;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)nbx, g.mtiles), dim3(512), lds, s, x, wpack, bias, y, g);
+    const int rc = check_launch("igemm_wino");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+}  // namespace faoctasr

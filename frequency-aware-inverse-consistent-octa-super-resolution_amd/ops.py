@@ -40,9 +40,10 @@ import weakref
 #: bumped whenever weights change behind autograd's back (ParamArena.step updates them through raw pointers)
 weight_epoch = 0
 use_wpack = True
-#: convolution contraction precision: 0 = exact fp32 MFMA (default), 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate)
+#: convolution arithmetic: 0 = fp32 MFMA with Winograd F(2x2,3x3) on the stride-1 3x3 layers (default), 1 = fp32 MFMA direct only,
+#: 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate)
 conv_precision = 0
-PRECISIONS = {"f32": 0, "bf16x3": 2}
+PRECISIONS = {"f32": 0, "f32_direct": 1, "bf16x3": 2}
 _wpack_cache = {}
 
 
@@ -95,7 +96,7 @@ class _Conv2d(Function):
             raise RuntimeError("Calculated padded input size per channel: (%d x %d). Kernel size: (%d x %d). "
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 0, C, M, KH, KW, stride, pad, (IH, IW))
+        wp, wst = _wpack(w, 0, C, M, KH, KW, stride, pad, (N, IH, IW))
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
              conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
@@ -119,14 +120,14 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, 0, (IH, IW))
+                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, 0, (N, IH, IW))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
                      conv_precision, st)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
             else:
                 dx = torch.empty_like(x)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, pad, (IH, IW))
+                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, pad, (N, IH, IW))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
@@ -157,7 +158,7 @@ class _ConvTranspose2d(Function):
             raise _lib.KernelError("conv_transpose2d: input has %d channels, weight expects %d" % (C, Cw))
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 2, C, M, KH, KW, stride, pad, (IH, IW))
+        wp, wst = _wpack(w, 2, C, M, KH, KW, stride, pad, (N, IH, IW))
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
              ptr(wp), wst, conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
@@ -180,7 +181,7 @@ class _ConvTranspose2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wp, wst = _wpack(ctx.w_ref, 3, C, M, KH, KW, stride, pad, (IH, IW))
+            wp, wst = _wpack(ctx.w_ref, 3, C, M, KH, KW, stride, pad, (N, IH, IW))
             call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
                  conv_precision, st)
         if ctx.needs_input_grad[1]:

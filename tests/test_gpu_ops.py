@@ -67,6 +67,10 @@ CONV_CASES = [
     (2, 64, 48, 48, 64, 7, 1, 3, True, True, None),           # c3 out conv with bias
     (2, 64, 64, 64, 1, 3, 1, 1, False, False, "tanh"),        # c9 on the patch path (M = 1)
     (1, 7, 33, 45, 5, 5, 1, 2, False, True, None),            # 5x5, odd everything
+    # dense stride-1 3x3 with >= 128 (tile, channel-tile) blocks: the Winograd F(2x2,3x3) kernel
+    (4, 20, 33, 47, 70, 3, 1, 1, False, True, "lrelu"),       # odd height and width, channel and M tails, bias + activation
+    (4, 64, 64, 64, 64, 3, 1, 1, False, False, None),         # c8-like
+    (8, 256, 32, 32, 256, 3, 1, 1, False, False, None),       # c5 at the benchmark size: 256 blocks, 32 chunks
 ]
 
 
@@ -414,6 +418,27 @@ def test_losses_head_adamw(fa, O):
         arena.step()
     close(lin.weight.view(-1), pr, rtol=1e-6, atol=1e-7)
     assert lin.weight.data_ptr() == arena.flat.data_ptr()
+
+
+def test_conv2d_winograd_matches_direct(fa):
+    """precision 0 takes the Winograd kernel on this shape, precision 1 ("f32_direct") the direct implicit GEMM: both are fp32
+    and agree to rounding (relative L2 <= 5e-6), forward and input gradient."""
+    g = torch.Generator().manual_seed(7)
+    x, w = dev(torch.randn(4, 48, 66, 70, generator=g)), dev(torch.randn(80, 48, 3, 3, generator=g) * 0.05)
+    cot = dev(torch.randn(4, 80, 66, 70, generator=g))
+    res = {}
+    for prec in (0, 1):
+        fa.ops.conv_precision = prec
+        try:
+            xd = x.clone().requires_grad_(True)
+            out = fa.ops.conv2d(xd, w, None, 1, 1, False, None, 0.2)
+            out.backward(cot)
+            res[prec] = (out.detach(), xd.grad)
+        finally:
+            fa.ops.conv_precision = 0
+    assert not torch.equal(res[0][0], res[1][0])          # different algorithms really ran
+    assert rel_l2(res[0][0], res[1][0]) < 5e-6
+    assert rel_l2(res[0][1], res[1][1]) < 5e-6
 
 
 SPLIT_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] // c[6] >= 24]
