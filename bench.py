@@ -177,7 +177,8 @@ def main():
                 traffic = json.load(open(tpath)).get("igemm_gather_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": "igemm_patch_kernel + igemm_gather_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
+        roof = {"bound": "mfma", "kernel": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3) + igemm_patch_kernel + igemm_gather_kernel: conv forward + input gradient on the "
+                          "f32 MFMA; achieved = direct-convolution (algorithmic) FLOP / time"
                 if args.precision == "f32" else "igemm_bf16x3_kernel (+ f32 kernels on narrow maps), f32-equivalent FLOP", "achieved": round(ach, 2),
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": cnt // nroof, "avg_launch_us": round(1e3 * ms / cnt, 2),

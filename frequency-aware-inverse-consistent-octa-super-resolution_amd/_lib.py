@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfaoctasr.so")
+LIB_PATH = os.environ.get("FAOCTASR_LIB") or os.path.join(_HERE, "libfaoctasr.so")      # override: kernel-variant experiments (tools/variants.py)
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIG = {

@@ -24,6 +24,10 @@
 #include "common.h"
 #include "igemm_geom.h"
 
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0      // diagnostics, compile time (tools/variants.py): 1 no MFMA, 2 no fragment reads, 4 no patch loads, 8 no V stores, 16 no U DMA, 32 no output stores
+#endif
+
 namespace faoctasr {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * g.C * chw), 0, (int)((long)g.C * chw * 4), 0x00020000);
         };
         auto load_d = [&](int ch) {
+            if constexpr ((WINO_ABLATE & 4) != 0) return;
             const unsigned coff = 4u * (unsigned)((ch * WN_KC + cl) * (int)chw);       // past the range for c >= C: reads 0
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
                     d[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, coff + rowoff[r] + coloff[c], 0, 0));
         };
         auto store_v = [&](int buf) {
+            if constexpr ((WINO_ABLATE & 8) != 0) return;
             float* vd = vdst0 + buf * WN_V_FLOATS;
             float t[4][4];
 #pragma unroll
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             }
         };
         auto issue_U = [&](int ch, int buf) {
+            if constexpr ((WINO_ABLATE & 16) != 0) return;
             const float* src = usrc + (long)ch * WN_U_FLOATS;
             float* dst = U_lds + buf * WN_U_FLOATS;
 #pragma unroll
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     auto st = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int nt = j >> 3, r = (j >> 1) & 3, a2 = j & 1;
-        if (pmask & (1u << j)) {
+        if ((pmask & (1u << j)) && (WINO_ABLATE & 32) == 0) {
             float* p = pbase + r * ohw + (long)(2 * nt + a2) * g.OW;
             if (pair_ok) {
                 *reinterpret_cast<f32x2*>(p) = pend[j];
@@ -285,29 +292,39 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             if (pmask) st_pair(ch);
             // fragment reads run two xi steps (8 MFMAs = 256 cycles) ahead of their use
             f32x2 a[3], b0[3], b1[3];
+            if constexpr ((WINO_ABLATE & 2) != 0) {
+                for (int i = 0; i < 3; ++i) a[i] = b0[i] = b1[i] = f32x2{(float)ua, (float)vb};
+            } else {
             asm volatile("ds_read_b64 %0, %1" : "=v"(a[0]) : "v"(ua));
             asm volatile("ds_read_b64 %0, %1" : "=v"(b0[0]) : "v"(vb));
             asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(b1[0]) : "v"(vb));
             asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(a[1]) : "v"(ua));
             asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(b0[1]) : "v"(vb));
             asm volatile("ds_read_b64 %0, %1 offset:1152" : "=v"(b1[1]) : "v"(vb));
+            }
             static_for<0, 16>([&](auto ic) {
                 constexpr int xi = decltype(ic)::value;
                 constexpr int cur = xi % 3, nx2 = (xi + 2) % 3;
-                if constexpr (xi + 2 < 16) {
+                if constexpr ((WINO_ABLATE & 2) != 0) {
+                } else if constexpr (xi + 2 < 16) {
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[nx2]) : "v"(ua), "n"((xi + 2) * 2048));
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b0[nx2]) : "v"(vb), "n"((xi + 2) * 1024));
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b1[nx2]) : "v"(vb), "n"((xi + 2) * 1024 + 128));
                     asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
+                } else if constexpr ((WINO_ABLATE & 2) != 0) {
                 } else if constexpr (xi + 1 < 16) {
                     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
                 }
+                if constexpr ((WINO_ABLATE & 1) == 0) {
                 acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][0], b0[cur][0], acc[xi][0], 0, 0, 0);
                 acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][0], b1[cur][0], acc[xi][1], 0, 0, 0);
                 acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][1], b0[cur][1], acc[xi][0], 0, 0, 0);
                 acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][1], b1[cur][1], acc[xi][1], 0, 0, 0);
+                } else {
+                    acc[xi][0][0] += a[cur][0] + b0[cur][0] + b1[cur][1];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             asm volatile("s_barrier" ::: "memory");                      // all LDS reads of this slab retired (lgkmcnt(0) above)
