@@ -93,6 +93,46 @@ def cpu_baseline(H, budget_s=15.0):
                       % (steps, H, H, B, nt, total)}
 
 
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def hbm_kernels(device, images=512, H=256):
+    """HBM roofline lines of the frequency-path kernels north_star names (Haar DWT level, SSIM window): algorithmic bytes
+     / HIP-event time on `images` 256x256 planes (134 MB per tensor, far beyond the 256 MB MALL for the pair)."""
+    from faoctasr import ops
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.rand(images, 1, H, H, generator=g).to(device)
+    b = torch.rand(images, 1, H, H, generator=g).to(device)
+    plane = images * H * H * 4
+
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e-3
+
+    out = []
+    with torch.no_grad():
+        for name, fn, nbytes in (("haar_dwt2d_fwd (DWTForward level, AFB2D)", lambda: ops.haar_afb2d(a), 2 * plane),
+                                 ("ssim_fwd (11x11 Gaussian window SSIM mean)", lambda: ops.ssim(a, b), 2 * plane)):
+            t = timed(fn)
+            gbs = nbytes / t / 1e9
+            out.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes, "us": round(t * 1e6, 1),
+                        "sample": "%d planes of %dx%d fp32" % (images, H, H)})
+            if name.startswith("ssim"):
+                # two 11-tap passes over five moment maps: ~270 FLOP per pixel against 8 bytes (34 FLOP/B, above the machine
+                # balance of ~20): the window kernel is bound by the fp32 vector pipe, not by HBM
+                fl = 270.0 * images * H * H
+                out[-1]["note"] = "VALU-bound (34 FLOP/B): %.1f TFLOP/s of the 157.3 TFLOP/s packed-fp32 vector peak" % (fl / t / 1e12)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,6 +246,22 @@ def main():
                                          "dtype": "conv fwd+dgrad on bf16 MFMA with hi/lo-split operands (3 MFMAs per product, fp32 accumulate); "
                                                   "wgrad and everything else f32",
                                          "parity": "step-0 losses within 1e-4, gradient norms within 2.3e-4 of the f32 path (tests/test_gpu_step.py)"}
+    # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
+    if rank == 0 and world == 1 and not args.no_graph:
+        gs = faoctasr.GraphedTrainStep(ts, real_A, real_B)
+        for _ in range(2):
+            gs.step(real_A, real_B)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gs.step(real_A, real_B)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        extra["hipgraph_step"] = {"value": round(B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
+                                  "note": "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"}
+        del gs
+    if rank == 0 and world == 1 and not args.no_roofline:
+        extra["roofline_hbm"] = hbm_kernels(device)
     if distributed:
         dist.barrier()
 

@@ -602,8 +602,8 @@ __global__ void mean_mix_bwd_kernel(const float* __restrict__ g, float* __restri
 }
 
 // torch.optim.AdamW single-tensor arithmetic order: decay, moments, bias corrections, update
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2, float gscale) {
+__device__ __forceinline__ void adamw_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                           float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2, float gscale) {
     const long stride = (long)gridDim.x * blockDim.x;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -633,6 +633,18 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         const float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
         p[i] = pk - step_size * (m[i] / denom);
     }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float step_size, float inv_sqrt_bc2, float gscale) {
+    adamw_body(p, g, m, v, n, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2, gscale);
+}
+
+// the same update with its scalars read from device memory, so that a captured hipGraph replays with the step's own learning
+// rate and bias corrections: hyper = {lr, beta1, beta2, eps, weight_decay, lr / bc1, 1 / sqrt(bc2), grad_scale}
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                 const float* __restrict__ hyper) {
+    adamw_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]);
 }
 
 }  // namespace faoctasr
@@ -869,6 +881,13 @@ int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
     return check_launch("adamw");
+}
+
+int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, faoctasr_stream_t stream) {
+    if (!p || !g || !m || !v || !hyper) return fail(FAOCTASR_EINVAL, "adamw_step_dev: null pointer");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper);
+    return check_launch("adamw_dev");
 }
 
 }  // extern "C"

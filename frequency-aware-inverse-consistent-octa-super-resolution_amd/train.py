@@ -7,13 +7,17 @@ data-parallel exchange is one all-reduce per phase), the targets and the replay 
 ``step(real_A, real_B)`` is one loop-body iteration.  The only semantic extension is the batched
 per-sample frequency split (the reference supports batch 1 only: SURVEY.md fact 3).
 """
+import math
+import random
+import struct
+
 import torch
 import torch.distributed as dist
 
 from . import ops
 from ._lib import call, ptr, stream_ptr
 from .model import FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A
-from .utils import ReplayBuffer, set_requires_grad, weights_init_normal
+from .utils import DeviceReplayBuffer, ReplayBuffer, set_requires_grad, weights_init_normal
 from .wavelets import DWTForward
 
 # parameters that exist in the reference's state_dict but never receive a gradient
@@ -66,11 +70,23 @@ class ParamArena:
         into the AdamW kernel's grad_scale."""
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
-    def step(self, grad_scale=1.0):
-        self.step_count += 1
-        call("adamw_step", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, self.lr, self.betas[0],
-             self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream_ptr())
+    def step(self, grad_scale=1.0, hyper=None):
+        """``hyper``: device tensor of 8 floats (``hyper_values``) -- the captured-graph form, whose scalars are read on the device."""
+        if hyper is None:
+            self.step_count += 1
+            call("adamw_step", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, self.lr, self.betas[0],
+                 self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream_ptr())
+        else:
+            call("adamw_step_dev", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, ptr(hyper), stream_ptr())
         ops.invalidate_weight_cache()      # the kernel changed the weights through raw pointers: packed images are stale
+
+    def hyper_values(self, step, grad_scale=1.0):
+        """The 8 scalars of ``faoctasr_adamw_step_dev`` for optimizer step ``step`` (>= 1), rounded exactly as ``faoctasr_adamw_step``
+        rounds its float arguments."""
+        f32 = lambda v: struct.unpack("f", struct.pack("f", v))[0]
+        lr, b1, b2 = f32(self.lr), f32(self.betas[0]), f32(self.betas[1])
+        bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+        return [lr, b1, b2, f32(self.eps), f32(self.weight_decay), f32(lr / bc1), f32(1.0 / math.sqrt(bc2)), f32(grad_scale)]
 
 
 class TrainStep:
@@ -157,8 +173,9 @@ class TrainStep:
         L["loss_G"] = total
         return L
 
-    def step(self, real_A, real_B, sync=False, keep=False):
-        """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats)."""
+    def step(self, real_A, real_B, sync=False, keep=False, _static=None):
+        """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats).
+        ``_static`` (GraphedTrainStep): device tensors replacing the host-decided pieces -- replay-buffer index plans and AdamW scalars."""
         B = real_A.shape[0]
         ones, zeros = self.targets(B)
         ops.conv_precision = ops.PRECISIONS[self.precision]
@@ -170,19 +187,19 @@ class TrainStep:
         L["loss_G"].backward()
         if self.distributed:
             self.opt_G.all_reduce(self.group)
-        self.opt_G.step(1.0 / self.world)
+        self.opt_G.step(1.0 / self.world, None if _static is None else _static["hyper_G"])
         # (3) discriminators, train.py:242-269
         set_requires_grad([self.netD_A, self.netD_B], True)
         self.opt_D.zero_grad()
-        fake_A = self.fake_A_buffer.push_and_pop(o["fake_A"])
+        fake_A = self.fake_A_buffer.push_and_pop(o["fake_A"]) if _static is None else self.fake_A_buffer.apply(o["fake_A"], *_static["plan_A"])
         L["loss_D_A"] = ops.mse_loss(self.netD_A(real_A), ones, 0.5) + ops.mse_loss(self.netD_A(fake_A.detach()), zeros, 0.5)
         L["loss_D_A"].backward()
-        fake_B = self.fake_B_buffer.push_and_pop(o["fake_B"])
+        fake_B = self.fake_B_buffer.push_and_pop(o["fake_B"]) if _static is None else self.fake_B_buffer.apply(o["fake_B"], *_static["plan_B"])
         L["loss_D_B"] = ops.mse_loss(self.netD_B(real_B), ones, 0.5) + ops.mse_loss(self.netD_B(fake_B.detach()), zeros, 0.5)
         L["loss_D_B"].backward()
         if self.distributed:
             self.opt_D.all_reduce(self.group)
-        self.opt_D.step(1.0 / self.world)
+        self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
         ops.conv_precision = 0
         out = {k: v.detach() for k, v in L.items()}
         if sync:
@@ -211,3 +228,93 @@ class TrainStep:
                     sq += float((p.grad.double() ** 2).sum())
             r[name] = sq ** 0.5
         return r
+
+
+class GraphedTrainStep:
+    """The whole train step as ONE captured hipGraph (BASELINE config 5): ~3000 kernel launches per step become one
+    graph launch, which removes the host enqueue time (39 ms/step) from small-batch steps.
+
+    What varies from step to step is moved off the host path: the replay buffers become ``DeviceReplayBuffer``s (the reference's
+    random decisions are still drawn on the host, in the reference's order, but reach the device as two small index tensors),
+    and AdamW reads its learning rate and bias corrections from device memory (``faoctasr_adamw_step_dev``).  Capturing does not
+    advance the training state: the warm-up steps that populate the allocator, the packed-weight buffers and the cached
+    circulants run on a snapshot that is restored before the capture.  Single process only (an RCCL exchange inside a capture
+    is not attempted)."""
+
+    def __init__(self, ts, real_A, real_B, warmup=2):
+        if ts.distributed:
+            raise RuntimeError("GraphedTrainStep: data-parallel steps are not captured; use TrainStep.step")
+        self.ts = ts
+        dev = ts.device
+        B = real_A.shape[0]
+        self.real_A, self.real_B = real_A.detach().clone(), real_B.detach().clone()
+        ts.fake_A_buffer = DeviceReplayBuffer.adopt(ts.fake_A_buffer)
+        ts.fake_B_buffer = DeviceReplayBuffer.adopt(ts.fake_B_buffer)
+        for b in (ts.fake_A_buffer, ts.fake_B_buffer):
+            b._ensure(self.real_A)
+        self._bns = [m for net in (ts.netG_A2B, ts.netG_B2A, ts.netD_A, ts.netD_B) for m in net.modules() if hasattr(m, "_pending_batches")]
+        snap = self._snapshot()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                ts.step(self.real_A, self.real_B)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._restore(snap)
+        mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+        self._static = {"plan_A": (mk(B, torch.long), mk(B, torch.long)), "plan_B": (mk(B, torch.long), mk(B, torch.long)),
+                        "hyper_G": mk(8, torch.float32), "hyper_D": mk(8, torch.float32)}
+        for k in ("plan_A", "plan_B"):                                   # valid indices for the capture pass itself
+            self._static[k][0].fill_(ts.fake_A_buffer.max_size + 1)
+            self._static[k][1].fill_(ts.fake_A_buffer.max_size)
+        pend = [m._pending_batches for m in self._bns]
+        ops.invalidate_weight_cache()                                    # every first use inside the graph packs its weights
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.losses = ts.step(self.real_A, self.real_B, _static=self._static)
+        self._bn_delta = [m._pending_batches - p for m, p in zip(self._bns, pend)]
+        for m, p in zip(self._bns, pend):                                # the capture pass executed nothing
+            m._pending_batches = p
+        ops.invalidate_weight_cache()
+
+    def _snapshot(self):
+        ts = self.ts
+        return {"arenas": [(a, a.flat.clone(), a.exp_avg.clone(), a.exp_avg_sq.clone(), a.step_count) for a in (ts.opt_G, ts.opt_D)],
+                "buffers": [(b, b.clone()) for net in (ts.netG_A2B, ts.netG_B2A, ts.netD_A, ts.netD_B) for b in net.buffers()],
+                "pending": [m._pending_batches for m in self._bns],
+                "replay": [(r, r.count, r.store.clone()) for r in (ts.fake_A_buffer, ts.fake_B_buffer)],
+                "random": random.getstate()}
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for a, flat, m, v, n in snap["arenas"]:
+                a.flat.copy_(flat); a.exp_avg.copy_(m); a.exp_avg_sq.copy_(v); a.step_count = n
+            for b, val in snap["buffers"]:
+                b.copy_(val)
+            for r, count, store in snap["replay"]:
+                r.count = count
+                r.store.copy_(store)
+        for m, p in zip(self._bns, snap["pending"]):
+            m._pending_batches = p
+        random.setstate(snap["random"])
+        ops.invalidate_weight_cache()
+
+    def step(self, real_A, real_B, sync=False):
+        """One train step = one graph launch.  The returned loss tensors are the graph's static outputs (overwritten by the next step)."""
+        ts = self.ts
+        B = self.real_A.shape[0]
+        self.real_A.copy_(real_A, non_blocking=True)
+        self.real_B.copy_(real_B, non_blocking=True)
+        for key, buf in (("plan_A", ts.fake_A_buffer), ("plan_B", ts.fake_B_buffer)):      # the reference's draw order: A, then B
+            src, dst = buf.plan(B)
+            self._static[key][0].copy_(torch.tensor(src, dtype=torch.long))
+            self._static[key][1].copy_(torch.tensor(dst, dtype=torch.long))
+        for key, opt in (("hyper_G", ts.opt_G), ("hyper_D", ts.opt_D)):
+            opt.step_count += 1
+            self._static[key].copy_(torch.tensor(opt.hyper_values(opt.step_count, 1.0), dtype=torch.float32))
+        self.graph.replay()
+        for m, d in zip(self._bns, self._bn_delta):
+            m._pending_batches += d
+        ops.invalidate_weight_cache()
+        return {k: float(v) for k, v in self.losses.items()} if sync else self.losses

@@ -36,6 +36,77 @@ class ReplayBuffer:
         return torch.cat(to_return)
 
 
+class DeviceReplayBuffer:
+    """``ReplayBuffer`` with the history in ONE device tensor (the replay buffer of a hipGraph-captured step).
+
+    The decisions are the reference's (utils.py:37-51): the same ``random.uniform`` / ``random.randint`` draws in the same order,
+    made on the host by ``plan``; ``apply`` is then a fixed-shape gather + scatter driven by two index tensors, so the device
+    work is identical from call to call and can be captured.  Row ``max_size`` of the store is a trash row for elements that are
+    not kept.  Index convention of ``plan``: source ``i < max_size`` = history row ``i``; ``max_size + 1 + j`` = element ``j``
+    of the incoming batch (an earlier element of the same call that was just written to the row being read)."""
+
+    def __init__(self, max_size=50):
+        assert max_size > 0, "Empty buffer or trying to create a black hole. Be careful."
+        self.max_size = max_size
+        self.count = 0
+        self.store = None
+
+    @classmethod
+    def adopt(cls, host_buffer):
+        """Continue a host-side ``ReplayBuffer`` (its images move into the device store)."""
+        if isinstance(host_buffer, cls):
+            return host_buffer
+        b = cls(host_buffer.max_size)
+        if host_buffer.data:
+            b._ensure(host_buffer.data[0])
+            b.store[:len(host_buffer.data)].copy_(torch.cat(host_buffer.data))
+            b.count = len(host_buffer.data)
+        return b
+
+    def _ensure(self, like):
+        if self.store is None:
+            self.store = torch.zeros((self.max_size + 1,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+
+    def plan(self, batch):
+        """Host decisions for one call: (source indices, destination rows), two lists of length ``batch``."""
+        src, writer = [], {}
+        for j in range(batch):
+            own = self.max_size + 1 + j
+            if self.count < self.max_size:
+                writer[self.count] = j
+                self.count += 1
+                src.append(own)
+            elif random.uniform(0, 1) > 0.5:
+                i = random.randint(0, self.max_size - 1)
+                src.append(self.max_size + 1 + writer[i] if i in writer else i)
+                writer[i] = j
+            else:
+                src.append(own)
+        dst = [self.max_size] * batch                       # trash row unless this element is the last writer of a row
+        for row, j in writer.items():
+            dst[j] = row
+        return src, dst
+
+    def apply(self, data, src, dst):
+        """Device part: ``src`` / ``dst`` int64 tensors of length batch (see ``plan``)."""
+        data = data.detach()
+        self._ensure(data)
+        pool = torch.cat([self.store, data])
+        out = pool.index_select(0, src)
+        self.store.index_copy_(0, dst, data)
+        return out
+
+    def push_and_pop(self, data):
+        src, dst = self.plan(data.shape[0])
+        dev = data.device
+        return self.apply(data, torch.tensor(src, dtype=torch.long, device=dev), torch.tensor(dst, dtype=torch.long, device=dev))
+
+    @property
+    def data(self):
+        """The history as the reference's list of (1, C, H, W) tensors."""
+        return [] if self.store is None else [self.store[i:i + 1] for i in range(self.count)]
+
+
 class LambdaLR:
     """utils.py:53-61."""
 

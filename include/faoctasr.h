@@ -178,6 +178,9 @@ int faoctasr_mean_mix_bwd(const float* g, float* da, float* db, int N, int La, i
 /* ---- optimizer: torch.optim.AdamW step (train.py:102-103,239,269) over one flat arena -------- */
 int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int step, float grad_scale, faoctasr_stream_t stream);
+/* The same update with the scalars in DEVICE memory (for a hipGraph-captured step, SURVEY 8f-1: the graph replays with each
+ * step's own values): hyper[8] = {lr, beta1, beta2, eps, weight_decay, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), grad_scale}. */
+int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, faoctasr_stream_t stream);
 
 /* ---- utility ---------------------------------------------------------------------------------- */
 int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream);

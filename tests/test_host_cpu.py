@@ -122,3 +122,54 @@ def test_wavelet_module_interface_cpu():
     with pytest.raises(ValueError):
         faoctasr.wavelets.mode_to_int("bogus")
     assert faoctasr.wavelets.int_to_mode(faoctasr.wavelets.mode_to_int("reflect")) == "reflect"
+
+
+def test_device_replay_buffer_matches_host_buffer():
+    """DeviceReplayBuffer (one store tensor + index plans, the captured-graph form) returns what the reference-order ReplayBuffer
+    returns for the same ``random`` seed, including same-call read-after-write on a full buffer, and ends with the same history."""
+    import random
+    import torch
+    fa = faoctasr
+    for max_size, batch, calls in ((5, 3, 12), (4, 6, 8), (50, 8, 20)):
+        random.seed(99)
+        host = fa.ReplayBuffer(max_size)
+        outs_h = []
+        g = torch.Generator().manual_seed(1)
+        batches = [torch.rand(batch, 1, 4, 4, generator=g) for _ in range(calls)]
+        for b in batches:
+            outs_h.append(host.push_and_pop(b))
+        random.seed(99)
+        dev = fa.DeviceReplayBuffer(max_size)
+        for b, ref in zip(batches, outs_h):
+            assert torch.equal(dev.push_and_pop(b), ref)
+        assert len(dev.data) == len(host.data)
+        for x, y in zip(dev.data, host.data):
+            assert torch.equal(x, y)
+        # adopting a host buffer mid-run continues identically
+        random.seed(5)
+        h2 = fa.ReplayBuffer(max_size)
+        for b in batches[:3]:
+            h2.push_and_pop(b)
+        d2 = fa.DeviceReplayBuffer.adopt(h2)
+        st = random.getstate()
+        r1 = [h2.push_and_pop(b) for b in batches[3:]]
+        random.setstate(st)
+        r2 = [d2.push_and_pop(b) for b in batches[3:]]
+        for x, y in zip(r1, r2):
+            assert torch.equal(x, y)
+
+
+def test_adamw_hyper_values_match_scalar_rounding():
+    """ParamArena.hyper_values (the device-side scalars of the captured step) = the float arguments faoctasr_adamw_step derives."""
+    import numpy as np
+    import torch
+    fa = faoctasr
+    arena = fa.ParamArena([("w", torch.nn.Parameter(torch.zeros(8)))], lr=1.3e-4)
+    for step in (1, 2, 10, 1000):
+        h = arena.hyper_values(step, 0.125)
+        b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+        lr = float(np.float32(1.3e-4))
+        assert h[0] == lr and h[1] == b1 and h[2] == b2
+        assert h[5] == float(np.float32(lr / (1.0 - b1 ** step)))
+        assert h[6] == float(np.float32(1.0 / np.sqrt(1.0 - b2 ** step)))
+        assert h[7] == 0.125
