@@ -10,6 +10,7 @@ from .model import (Discriminator, FS_DiscriminatorA, FS_DiscriminatorB, Network
                     ResnetGenerator, TVLoss, UnetGenerator, UnetSkipConnectionBlock, shallowNet)
 from .evaluate import evaluate_pairs, super_resolve
 from .ssim import SSIM, ssim
+from .data import GpuTransformA, GpuTransformB, crop_resize_normalize, random_crop_offsets
 from .train import GraphedTrainStep, ParamArena, TrainStep, live_parameters
 from .utils import (DeviceReplayBuffer, LambdaLR, ReplayBuffer, frequency_split, high_pass, low_pass, psnr, set_requires_grad, weights_init_normal)
 from .wavelets import AFB2D, SFB2D, DWTForward, DWTInverse

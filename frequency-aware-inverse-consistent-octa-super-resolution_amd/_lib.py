@@ -52,6 +52,7 @@ _SIG = {
     "mean_mix_bwd": (_I, "ppp iii ff p"),
     "adamw_step": (_I, "pppp l fffff i f p"),
     "adamw_step_dev": (_I, "pppp l p p"),
+    "prep_crop_resize": (_I, "pppp iiiii ff p"),
     "fill": (_I, "p l f p"),
 }
 _CODE = {"p": _P, "i": _I, "l": _L, "f": _F}

@@ -647,6 +647,54 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
     adamw_body(p, g, m, v, n, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]);
 }
 
+// ---- input pipeline (train.py:129-140): ToTensor -> RandomCrop -> [Resize bicubic] -> Normalize, fused --------------------
+// torch's upsample_bicubic2d (align_corners = False, A = -0.75, border indices clamped), the arithmetic torchvision's tensor
+// Resize(BICUBIC) runs: src = (dst + 0.5) * in/out - 0.5, taps at floor(src) - 1 .. + 2, rows interpolated first.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+    constexpr float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ void prep_crop_resize_kernel(const unsigned char* __restrict__ img, const int* __restrict__ tops, const int* __restrict__ lefts,
+                                        float* __restrict__ out, int N, int H, int W, int crop, int osz, float mean, float inv_std) {
+    const long total = (long)N * osz * osz;
+    const float scale = (float)crop / (float)osz;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % osz), oy = (int)((i / osz) % osz), n = (int)(i / ((long)osz * osz));
+        const unsigned char* src = img + (long)n * H * W + (long)tops[n] * W + lefts[n];
+        float v;
+        if (osz == crop) {
+            v = (float)src[(long)oy * W + ox] / 255.f;                 // true division: ToTensor's .div(255)
+        } else {
+            const float sy = ((float)oy + 0.5f) * scale - 0.5f, sx = ((float)ox + 0.5f) * scale - 0.5f;
+            const float fy = floorf(sy), fx = floorf(sx);
+            float cy[4], cx[4];
+            cubic_coeffs(sy - fy, cy);
+            cubic_coeffs(sx - fx, cx);
+            const int iy = (int)fy, ix = (int)fx;
+            v = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                int yy = iy - 1 + a;
+                yy = yy < 0 ? 0 : (yy > crop - 1 ? crop - 1 : yy);
+                float row = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int xx = ix - 1 + b;
+                    xx = xx < 0 ? 0 : (xx > crop - 1 ? crop - 1 : xx);
+                    row += cx[b] * ((float)src[(long)yy * W + xx] / 255.f);
+                }
+                v += cy[a] * row;
+            }
+        }
+        out[i] = (v - mean) * inv_std;
+    }
+}
+
 }  // namespace faoctasr
 
 using namespace faoctasr;
@@ -881,6 +929,17 @@ int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
     return check_launch("adamw");
+}
+
+int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const int* lefts, float* out, int N, int H, int W, int crop,
+                              int out_size, float mean, float std, faoctasr_stream_t stream) {
+    if (!img || !tops || !lefts || !out) return fail(FAOCTASR_EINVAL, "prep_crop_resize: null pointer");
+    if (N < 0 || crop <= 0 || out_size <= 0 || crop > H || crop > W || std == 0.f) return fail(FAOCTASR_EINVAL, "prep_crop_resize: bad shape");
+    const long total = (long)N * out_size * out_size;
+    if (total == 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(prep_crop_resize_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, img, tops, lefts, out, N, H,
+                       W, crop, out_size, mean, 1.f / std);
+    return check_launch("prep_crop_resize");
 }
 
 int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, faoctasr_stream_t stream) {

@@ -182,6 +182,14 @@ int faoctasr_adamw_step(float* p, const float* g, float* m, float* v, long n, fl
  * step's own values): hyper[8] = {lr, beta1, beta2, eps, weight_decay, lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), grad_scale}. */
 int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, faoctasr_stream_t stream);
 
+/* ---- input pipeline: the tensor transforms of train.py:129-140 fused into one pass ---------------------------
+ * img [N,H,W] uint8 grayscale (what Image.open(..).convert('L') + ToTensor hold before the /255), tops/lefts [N] device ints =
+ * the RandomCrop offsets (drawn by the caller), out [N,1,out_size,out_size] fp32:
+ *   out = (resize(crop(img)/255) - mean) / std,  resize = torch bicubic (align_corners false, A = -0.75) when out_size != crop
+ * transforms_A = crop 128 -> 256 bicubic; transforms_B = crop 256, no resize (the Normalize/RandomCrop order there commutes). */
+int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const int* lefts, float* out, int N, int H, int W,
+                              int crop, int out_size, float mean, float std, faoctasr_stream_t stream);
+
 /* ---- utility ---------------------------------------------------------------------------------- */
 int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream);
 

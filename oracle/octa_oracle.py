@@ -681,3 +681,24 @@ def psnr(y, gt, data_range=2.0):
     """skimage.metrics.peak_signal_noise_ratio(y, gt, data_range=2) = 10 log10(4/MSE) (utils.py:209)."""
     mse = float(((y.double() - gt.double()) ** 2).mean())
     return 10.0 * math.log10(data_range ** 2 / mse)
+
+
+# ------------------------------------------------------------------------------------------------
+# input transforms (train.py:129-140) -- the loader's tensor arithmetic, for the device-side pipeline (SURVEY 8f-4)
+# ------------------------------------------------------------------------------------------------
+def transform_A(img_u8, top, left, size_A=128):
+    """transforms_A on one decoded grayscale image (uint8 [H, W]) with the RandomCrop offsets given: ToTensor (/255),
+    crop, Resize((2*size_A, 2*size_A), BICUBIC), Normalize(0.5, 0.5).  torchvision is absent offline; its tensor ``Resize`` is
+    ``torch.nn.functional.interpolate(mode='bicubic', align_corners=False)`` (torchvision/transforms/_functional_tensor.py ``resize``;
+    antialiasing does not act on an upscale), which is what runs here."""
+    x = torch.as_tensor(img_u8).to(torch.float32).div(255.0)[None, None]
+    x = x[:, :, top:top + size_A, left:left + size_A]
+    x = torch.nn.functional.interpolate(x, size=(2 * size_A, 2 * size_A), mode="bicubic", align_corners=False)
+    return ((x - 0.5) / 0.5)[0]
+
+
+def transform_B(img_u8, top, left, size_B=256):
+    """transforms_B: ToTensor, Normalize(0.5, 0.5), RandomCrop(size_B)."""
+    x = torch.as_tensor(img_u8).to(torch.float32).div(255.0)[None]
+    x = (x - 0.5) / 0.5
+    return x[:, top:top + size_B, left:left + size_B]

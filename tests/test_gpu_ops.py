@@ -490,3 +490,29 @@ def test_conv_transpose2d_bf16x3(fa, case):
         fa.ops.conv_precision = 0
     assert rel_l2(out, ref) < 3e-5
     assert rel_l2(xd.grad, xr.grad) < 3e-5
+
+
+def test_input_pipeline_vs_oracle(fa, O):
+    """fused crop + bicubic x2 + normalise (transforms_A) and crop + normalise (transforms_B) against the oracle's
+    ATen restatement of train.py:129-140, including border crops (clamped bicubic taps) and a non-square source."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (5, 150, 201), dtype=torch.uint8, generator=g)
+    tops, lefts = [0, 22, 11, 0, 22], [0, 73, 40, 73, 0]
+    out = fa.crop_resize_normalize(img.cuda(), tops, lefts, 128, 256)
+    assert out.shape == (5, 1, 256, 256) and out.is_contiguous()
+    for i in range(5):
+        ref = O.transform_A(img[i], tops[i], lefts[i], 128)
+        close(out[i], ref, rtol=1e-5, atol=2e-6)
+    big = torch.randint(0, 256, (3, 300, 280), dtype=torch.uint8, generator=g)
+    tb, lb = [0, 44, 17], [24, 0, 9]
+    outb = fa.crop_resize_normalize(big.cuda(), tb, lb, 256, 256)
+    for i in range(3):
+        assert torch.equal(outb[i].cpu(), O.transform_B(big[i], tb[i], lb[i], 256))
+    # seeded crops follow torchvision's draw order (top, then left, per image)
+    gen = torch.Generator().manual_seed(11)
+    t1, l1 = fa.random_crop_offsets(4, 150, 201, 128, gen)
+    gen = torch.Generator().manual_seed(11)
+    exp = [(int(torch.randint(0, 23, (1,), generator=gen)), int(torch.randint(0, 74, (1,), generator=gen))) for _ in range(4)]
+    assert list(zip(t1, l1)) == exp
+    with pytest.raises(ValueError):
+        fa.crop_resize_normalize(img.cuda(), tops, lefts, 160, 320)
