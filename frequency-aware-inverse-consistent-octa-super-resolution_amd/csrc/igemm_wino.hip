@@ -17,8 +17,11 @@
 // over pixel tiles so the pipeline does not drain between tiles.
 //
 // LDS operand order: within a chunk the 8 channels are split as c = k + 4 j (k = 0..3 is the MFMA's K index = lane >> 4,
-// j = 0, 1 the two MFMAs of the chunk); element (xi, k, row, j) sits at ((xi * 4 + k) * ROWS + row) * 2 + j, so one
-// ds_read_b64 per lane fetches the operands of both MFMAs and every 8 lanes read 64 contiguous bytes (conflict-free).
+// j = 0, 1 the two MFMAs of the chunk); element (xi, k, row, j) sits at ((xi * 4 + k) * ROWS + (row ^ 16 (k & 1))) * 2 + j, so
+// one ds_read_b64 per lane fetches the operands of both MFMAs.  ds_read_b64 is serviced in two groups of 32 lanes over 64
+// banks: lanes 0-15 (k even) and 16-31 (k odd) of a group read 128 contiguous bytes each, and the XOR puts the odd-k rows'
+// 16-row blocks in the other half of the 256-byte bank line -- without it every fragment read was a 2-way conflict
+// (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).
 #include <type_traits>
 
 #include "common.h"
@@ -67,7 +70,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
         const int xi = (int)(li & 15); li >>= 4;
         const int ch = (int)(li % g.nchunks);
         const int mt = (int)(li / g.nchunks);
-        const int m = mt * WN_MT + ml, c = ch * WN_KC + k + 4 * j;
+        const int m = mt * WN_MT + (ml ^ (16 * (k & 1))), c = ch * WN_KC + k + 4 * j;      // slot ml holds row ml ^ 16 (k & 1)
         float v = 0.f;
         if (m < g.M && c < g.C) {
             const float* wp = w + (long)m * g.wsm + (long)c * g.wsc;
@@ -114,19 +117,60 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     if (producer) {
         // ================================================ PRODUCER ================================================
         // Slab q = (tile q / nchunks, chunk q % nchunks) of this block's tile sequence; the consumers work on slab q between
-        // barrier(q-1) and barrier(q).  In that interval the producers (1) transform the patch of slab q+1 (loaded one slab
-        // ago) into the other V buffer, (2) issue the weight DMA of slab q+2 into the third U buffer, (3) issue the patch loads
-        // of slab q+2.  (2) and (3) stay in flight across the barrier: vmcnt(24) retires everything older than this step's 8
-        // DMA rows and 16 loads.
+        // barrier(q-1) and barrier(q).  Two producer roles, so that each wave's memory counter tracks one kind of traffic:
+        //   waves 4-5 (TRANSFORM): thread = (tile, k) and the two channels k, k+4 of the chunk.  In step q they turn the patch
+        //       of slab q+1 (registers, loaded TWO steps ago) into V[(q+1)&1] and then issue the 32 loads of slab q+3 into the
+        //       same registers; the loads of slab q+2 are in flight meanwhile.  With only plain loads outstanding the compiler
+        //       counts vmcnt exactly (it must wait vmcnt(0) before an LDS store once an LDS-DMA is in flight in the same wave,
+        //       which made the prefetch one step deep and left ~3000 cycles of HBM latency exposed per slab: s_memtime trace).
+        //   waves 6-7 (WEIGHTS): LDS-DMA of the transformed-weight slab of slab q+2 into U[(q+2)%3], retired by the barrier's
+        //       vmcnt one step later.
         const int stid = tid & 255;
-        const int tile = stid & 31, cl = stid >> 5;                     // (tile, local channel 0..7)
+        const int nslab_u = nchunks;
+        const long my_tiles = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+        const long q_total = my_tiles * nchunks;
+        if (stid >= 128) {
+            // ---------------------------------------------- weights ----------------------------------------------
+            const int w2 = (stid >> 6) & 1;                              // 0, 1: rows w2, w2+2, ... of the 32-row slab
+            const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + lane * 4;
+            auto issue_U = [&](int ch, int buf) {
+                if constexpr ((WINO_ABLATE & 16) != 0) return;
+                const float* src = usrc + (long)ch * WN_U_FLOATS;
+                float* dst = U_lds + buf * WN_U_FLOATS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = w2 + 2 * i;                            // 1 KiB row of the 32 KiB slab
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 256),
+                                                     (__attribute__((address_space(3))) void*)(dst + r * 256), 16, 0, 0);
+                }
+            };
+            int ch_u = 0, ubuf = 1;
+            auto next_u = [&]() {
+                if (++ch_u == nslab_u) ch_u = 0;
+                issue_U(ch_u, ubuf);
+                ubuf = ubuf == 2 ? 0 : ubuf + 1;
+            };
+            issue_U(0, 0);
+            if (q_total > 1) next_u();                                   // slab 1 -> U[1]
+            // barrier(-1): slab 0's weights must have landed; slab 1's 16 rows may still fly
+            if (q_total > 1) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            for (long q = 0; q < q_total; ++q) {
+                const bool more = q + 2 < q_total;
+                if (more) next_u();                                      // slab q+2
+                // barrier(q): slab q+1's weights (issued one step ago) landed; this step's 16 rows may still fly
+                if (more) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            return;
+        }
+        // ------------------------------------------------ transform ------------------------------------------------
+        const int tile = stid & 31, kk = stid >> 5;                      // (tile, k 0..3); channels k and k+4
         const int tr = tile >> 4, tc = tile & 15;
-        const int kk = cl & 3, jj = cl >> 2;
-        float* const vdst0 = V_lds + ((kk * 32 + tile) * 2 + jj);       // + xi*256 floats, + buf*WN_V_FLOATS
-        const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + lane * 4;
+        f32x2* const vdst0 = reinterpret_cast<f32x2*>(V_lds) + (kk * 32 + (tile ^ (16 * (kk & 1))));     // + xi*128 pairs, + buf*2048 pairs
         unsigned rowoff[4], coloff[4];
-        float d[4][4];
         __amdgpu_buffer_rsrc_t srd;
+        float dA[2][16], dB[2][16];                                      // patches of even / odd slabs, [channel k / k+4][4x4]
         auto set_tile = [&](long tl) {
             int n, ty, tx;
             tile_coords(tl, n, ty, tx);
@@ -138,74 +182,67 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             }
             srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * g.C * chw), 0, (int)((long)g.C * chw * 4), 0x00020000);
         };
-        auto load_d = [&](int ch) {
+        auto load_d = [&](float (&d)[2][16], int ch) {
             if constexpr ((WINO_ABLATE & 4) != 0) return;
-            const unsigned coff = 4u * (unsigned)((ch * WN_KC + cl) * (int)chw);       // past the range for c >= C: reads 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int j = 0; j < 2; ++j) {
+                const unsigned coff = 4u * (unsigned)((ch * WN_KC + kk + 4 * j) * (int)chw);   // past the range for c >= C: reads 0
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    d[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, coff + rowoff[r] + coloff[c], 0, 0));
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        d[j][r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, coff + rowoff[r] + coloff[c], 0, 0));
+            }
         };
-        auto store_v = [&](int buf) {
+        auto store_v = [&](const float (&d)[2][16], int buf) {
             if constexpr ((WINO_ABLATE & 8) != 0) return;
-            float* vd = vdst0 + buf * WN_V_FLOATS;
-            float t[4][4];
+            f32x2* vd = vdst0 + buf * (WN_V_FLOATS / 2);
+            float t[2][4][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {                                // B^T d
-                t[0][c] = d[0][c] - d[2][c];
-                t[1][c] = d[1][c] + d[2][c];
-                t[2][c] = d[2][c] - d[1][c];
-                t[3][c] = d[1][c] - d[3][c];
-            }
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {                                // (.) B
-                vd[(r * 4 + 0) * 256] = t[r][0] - t[r][2];
-                vd[(r * 4 + 1) * 256] = t[r][1] + t[r][2];
-                vd[(r * 4 + 2) * 256] = t[r][2] - t[r][1];
-                vd[(r * 4 + 3) * 256] = t[r][1] - t[r][3];
-            }
-        };
-        auto issue_U = [&](int ch, int buf) {
-            if constexpr ((WINO_ABLATE & 16) != 0) return;
-            const float* src = usrc + (long)ch * WN_U_FLOATS;
-            float* dst = U_lds + buf * WN_U_FLOATS;
+                for (int c = 0; c < 4; ++c) {                            // B^T d
+                    t[j][0][c] = d[j][0 + c] - d[j][8 + c];
+                    t[j][1][c] = d[j][4 + c] + d[j][8 + c];
+                    t[j][2][c] = d[j][8 + c] - d[j][4 + c];
+                    t[j][3][c] = d[j][4 + c] - d[j][12 + c];
+                }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = wn + 4 * i;                               // 1 KiB row of the 32 KiB slab
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 256),
-                                                 (__attribute__((address_space(3))) void*)(dst + r * 256), 16, 0, 0);
+            for (int r = 0; r < 4; ++r) {                                // (.) B; one 8-byte store per Winograd position
+                vd[(r * 4 + 0) * 128] = f32x2{t[0][r][0] - t[0][r][2], t[1][r][0] - t[1][r][2]};
+                vd[(r * 4 + 1) * 128] = f32x2{t[0][r][1] + t[0][r][2], t[1][r][1] + t[1][r][2]};
+                vd[(r * 4 + 2) * 128] = f32x2{t[0][r][2] - t[0][r][1], t[1][r][2] - t[1][r][1]};
+                vd[(r * 4 + 3) * 128] = f32x2{t[0][r][1] - t[0][r][3], t[1][r][1] - t[1][r][3]};
             }
         };
-        auto barrier = [&](bool ahead) {
-            if (ahead) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        };
-        const long my_tiles = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-        const long q_total = my_tiles * nchunks;
-        long tl_load = blockIdx.x;                                      // tile / chunk of the look-ahead cursor
-        int ch_load = 0, ubuf = 1;
-        auto advance = [&]() {                                          // weights + patch loads of the next slab in sequence
+        long tl_load = blockIdx.x;                                      // (tile, chunk) of the patch-load cursor
+        int ch_load = 0;
+        auto next_load = [&](float (&d)[2][16]) {
             if (++ch_load == nchunks) {
                 ch_load = 0;
                 tl_load += gridDim.x;
                 set_tile(tl_load);
             }
-            issue_U(ch_load, ubuf);
-            ubuf = ubuf == 2 ? 0 : ubuf + 1;
-            load_d(ch_load);
+            load_d(d, ch_load);
         };
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        // prologue: slab 0 -> V[0]; slabs 1 and 2 in flight (dB, dA)
         set_tile(tl_load);
-        issue_U(0, 0);
-        load_d(0);
-        store_v(0);                                                      // slab 0 complete in LDS after the barrier
-        if (q_total > 1) advance();                                      // slab 1: weights -> U[1], patch -> registers
-        barrier(q_total > 1);
-        for (long q = 0; q < q_total; ++q) {
-            if (q + 1 < q_total) store_v((int)((q + 1) & 1));
-            const bool more = q + 2 < q_total;
-            if (more) advance();
-            barrier(more);
+        load_d(dA, 0);
+        if (q_total > 1) next_load(dB);
+        store_v(dA, 0);
+        if (q_total > 2) next_load(dA);
+        barrier();                                                       // barrier(-1)
+        for (long q = 0; q < q_total; q += 2) {
+            // step q (even): slab q+1 sits in dB
+            if (q + 1 < q_total) store_v(dB, 1);
+            if (q + 3 < q_total) next_load(dB);
+            barrier();
+            if (q + 1 >= q_total) break;
+            // step q+1 (odd): slab q+2 sits in dA
+            if (q + 2 < q_total) store_v(dA, 0);
+            if (q + 4 < q_total) next_load(dA);
+            barrier();
         }
         return;
     }
@@ -220,10 +257,16 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             for (int r = 0; r < 4; ++r) acc[xi][nt][r] = 0.f;
     const int l15 = lane & 15, lk = lane >> 4;
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned ua0 = lds0 + (unsigned)((lk * 64 + 16 * wn + l15) * 8);                               // + xi*2048 + buf*32768
-    const unsigned vb0 = lds0 + 3u * WN_U_FLOATS * 4u + (unsigned)((lk * 32 + l15) * 8);                  // + xi*1024 + nt*128 + buf*16384
+    const int sw = 16 * (lk & 1);
+    const unsigned ua0 = lds0 + (unsigned)((lk * 64 + ((16 * wn) ^ sw) + l15) * 8);                      // + xi*2048 + buf*32768
+    const unsigned vb0 = lds0 + 3u * WN_U_FLOATS * 4u + (unsigned)((lk * 32 + sw + l15) * 8);             // tiles 0-15:  + xi*1024 + buf*16384
+    const unsigned vc0 = lds0 + 3u * WN_U_FLOATS * 4u + (unsigned)((lk * 32 + (16 ^ sw) + l15) * 8);      // tiles 16-31
     const long ohw = (long)g.OH * g.OW;
     const bool pair_ok = (g.OW & 1) == 0;
+    const int m_base = mt * WN_MT + 16 * wn + 4 * lk;                   // this lane's 4 output channels: the same for every tile
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (bias && m_base + r < g.M) ? bias[m_base + r] : 0.f;
 
     // Finished tiles are not stored at once: the 16 (float2) results of a lane wait in registers and leave two per slab
     // during the next tile's reduction.  All blocks of the persistent grid run in step, so storing at the tile boundary would
@@ -287,7 +330,8 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         const long next_tile = tl + gridDim.x;
         const bool has_next = next_tile < total_tiles;
         for (int ch = 0; ch < nchunks; ++ch, ++slab) {
-            const unsigned ua = ua0 + (unsigned)ub * (WN_U_FLOATS * 4u), vb = vb0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u);
+            const unsigned ua = ua0 + (unsigned)ub * (WN_U_FLOATS * 4u), vb = vb0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u),
+                           vc = vc0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u);
             ub = ub == 2 ? 0 : ub + 1;
             if (pmask) st_pair(ch);
             // fragment reads run two xi steps (8 MFMAs = 256 cycles) ahead of their use
@@ -297,10 +341,10 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             } else {
             asm volatile("ds_read_b64 %0, %1" : "=v"(a[0]) : "v"(ua));
             asm volatile("ds_read_b64 %0, %1" : "=v"(b0[0]) : "v"(vb));
-            asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(b1[0]) : "v"(vb));
+            asm volatile("ds_read_b64 %0, %1" : "=v"(b1[0]) : "v"(vc));
             asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(a[1]) : "v"(ua));
             asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(b0[1]) : "v"(vb));
-            asm volatile("ds_read_b64 %0, %1 offset:1152" : "=v"(b1[1]) : "v"(vb));
+            asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(b1[1]) : "v"(vc));
             }
             static_for<0, 16>([&](auto ic) {
                 constexpr int xi = decltype(ic)::value;
@@ -309,7 +353,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
                 } else if constexpr (xi + 2 < 16) {
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[nx2]) : "v"(ua), "n"((xi + 2) * 2048));
                     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b0[nx2]) : "v"(vb), "n"((xi + 2) * 1024));
-                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b1[nx2]) : "v"(vb), "n"((xi + 2) * 1024 + 128));
+                    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b1[nx2]) : "v"(vc), "n"((xi + 2) * 1024));
                     asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[cur]), "+v"(b0[cur]), "+v"(b1[cur]));
                 } else if constexpr ((WINO_ABLATE & 2) != 0) {
                 } else if constexpr (xi + 1 < 16) {
@@ -335,7 +379,6 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             int n, ty, tx;
             tile_coords(tl, n, ty, tx);
             const int ox = 32 * tx + 2 * l15;
-            const int m_base = mt * WN_MT + 16 * wn + 4 * lk;
             pbase = y + ((long)n * g.M + m_base) * ohw + (long)(4 * ty) * g.OW + ox;
             px1 = ox + 1 < g.OW;
             pmask = 0;
@@ -349,15 +392,26 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
                         s0[b] = acc[0 + b][nt][r] + acc[4 + b][nt][r] + acc[8 + b][nt][r];
                         s1[b] = acc[4 + b][nt][r] - acc[8 + b][nt][r] - acc[12 + b][nt][r];
                     }
-                    const int m = m_base + r;
-                    const float bv = (bias && m < g.M) ? bias[m] : 0.f;
-                    pend[nt * 8 + r * 2 + 0] = f32x2{act_apply(s0[0] + s0[1] + s0[2] + bv, g.act, g.slope), act_apply(s0[1] - s0[2] - s0[3] + bv, g.act, g.slope)};
-                    pend[nt * 8 + r * 2 + 1] = f32x2{act_apply(s1[0] + s1[1] + s1[2] + bv, g.act, g.slope), act_apply(s1[1] - s1[2] - s1[3] + bv, g.act, g.slope)};
-                    if (m < g.M && ox < g.OW) {
+                    pend[nt * 8 + r * 2 + 0] = f32x2{s0[0] + s0[1] + s0[2] + bv[r], s0[1] - s0[2] - s0[3] + bv[r]};
+                    pend[nt * 8 + r * 2 + 1] = f32x2{s1[0] + s1[1] + s1[2] + bv[r], s1[1] - s1[2] - s1[3] + bv[r]};
+                    if (m_base + r < g.M && ox < g.OW) {
                         if (4 * ty + 2 * nt < g.OH) pmask |= 1u << (nt * 8 + r * 2);
                         if (4 * ty + 2 * nt + 1 < g.OH) pmask |= 1u << (nt * 8 + r * 2 + 1);
                     }
                 }
+            }
+            // one activation dispatch per tile (inlining the switch -- with tanhf -- at each of the 64 values made the epilogue a
+            // cold 7700-cycle instruction-cache walk: s_memtime trace)
+            if (g.act == FAOCTASR_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pend[j] = f32x2{fmaxf(pend[j][0], 0.f), fmaxf(pend[j][1], 0.f)};
+            } else if (g.act == FAOCTASR_ACT_LRELU) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    pend[j] = f32x2{pend[j][0] > 0.f ? pend[j][0] : pend[j][0] * g.slope, pend[j][1] > 0.f ? pend[j][1] : pend[j][1] * g.slope};
+            } else if (g.act == FAOCTASR_ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pend[j] = f32x2{tanhf(pend[j][0]), tanhf(pend[j][1])};
             }
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi)
