@@ -27,6 +27,16 @@
 #include "common.h"
 #include "igemm_geom.h"
 
+#ifndef WINO_TRACE
+#define WINO_TRACE 0       // diagnostics (tools/variants.py + tools/wino_trace.py): block 0 stamps s_memtime of its phases behind the bias vector
+#endif
+#if WINO_TRACE
+#define WTRACE(cond, base, q, k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (cond) && (q) >= 16 && (q) < 48) reinterpret_cast<unsigned*>(const_cast<float*>(bias))[(base) + ((q) - 16) * 4 + (k)] = (v); } while (0)
+#define WNOW() ((unsigned)__builtin_amdgcn_s_memtime())
+#else
+#define WTRACE(cond, base, q, k, v) do { } while (0)
+#define WNOW() 0u
+#endif
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0      // diagnostics, compile time (tools/variants.py): 1 no MFMA, 2 no fragment reads, 4 no patch loads, 8 no V stores, 16 no U DMA, 32 no output stores
 #endif
@@ -123,44 +133,61 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         //       same registers; the loads of slab q+2 are in flight meanwhile.  With only plain loads outstanding the compiler
         //       counts vmcnt exactly (it must wait vmcnt(0) before an LDS store once an LDS-DMA is in flight in the same wave,
         //       which made the prefetch one step deep and left ~3000 cycles of HBM latency exposed per slab: s_memtime trace).
-        //   waves 6-7 (WEIGHTS): LDS-DMA of the transformed-weight slab of slab q+2 into U[(q+2)%3], retired by the barrier's
-        //       vmcnt one step later.
+        //   waves 6-7 (WEIGHTS): the transformed-weight slab of slab q+2 into U[(q+2)%3] through registers (see below).
         const int stid = tid & 255;
         const int nslab_u = nchunks;
         const long my_tiles = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
         const long q_total = my_tiles * nchunks;
         if (stid >= 128) {
             // ---------------------------------------------- weights ----------------------------------------------
-            const int w2 = (stid >> 6) & 1;                              // 0, 1: rows w2, w2+2, ... of the 32-row slab
-            const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + lane * 4;
-            auto issue_U = [&](int ch, int buf) {
+            // Register staging (16 x global_load_dwordx4 -> 16 x ds_write_b128 per wave and slab), not LDS-DMA: back-to-back
+            // global_load_lds_dwordx4 of ONE wave issue at ~177 cycles each (s_memtime trace: 2850 cycles for a wave's 16
+            // rows, more than a consumer slab), plain loads pipeline.  Slab q+2 is stored during step q from registers loaded
+            // during step q-1 (two slabs in flight per wave were tried: slower, the L2 -> CU path is the limit); the loop is peeled like the transform loop so that the compiler's vmcnt counts stay exact.
+            const int w2 = (stid >> 6) & 1;                              // rows w2, w2+2, ... of the 32-row (1 KiB each) slab
+            const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + w2 * 256 + lane * 4;
+            float* const udst = U_lds + w2 * 256 + lane * 4;
+            f32x4w wr[16];
+            auto load_u = [&](int ch) {
                 if constexpr ((WINO_ABLATE & 16) != 0) return;
                 const float* src = usrc + (long)ch * WN_U_FLOATS;
-                float* dst = U_lds + buf * WN_U_FLOATS;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int r = w2 + 2 * i;                            // 1 KiB row of the 32 KiB slab
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 256),
-                                                     (__attribute__((address_space(3))) void*)(dst + r * 256), 16, 0, 0);
-                }
+                for (int i = 0; i < 16; ++i) wr[i] = *reinterpret_cast<const f32x4w*>(src + i * 512);
             };
-            int ch_u = 0, ubuf = 1;
-            auto next_u = [&]() {
+            auto store_u = [&](int buf) {
+                if constexpr ((WINO_ABLATE & 16) != 0) return;
+                float* dst = udst + buf * WN_U_FLOATS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4w*>(dst + i * 512) = wr[i];
+            };
+            int ch_u = 0, ubuf = 0;
+            auto next_load_u = [&]() {
                 if (++ch_u == nslab_u) ch_u = 0;
-                issue_U(ch_u, ubuf);
-                ubuf = ubuf == 2 ? 0 : ubuf + 1;
+                load_u(ch_u);
             };
-            issue_U(0, 0);
-            if (q_total > 1) next_u();                                   // slab 1 -> U[1]
-            // barrier(-1): slab 0's weights must have landed; slab 1's 16 rows may still fly
-            if (q_total > 1) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            for (long q = 0; q < q_total; ++q) {
-                const bool more = q + 2 < q_total;
-                if (more) next_u();                                      // slab q+2
-                // barrier(q): slab q+1's weights (issued one step ago) landed; this step's 16 rows may still fly
-                if (more) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            auto next_store_u = [&]() {
+                ubuf = ubuf == 2 ? 0 : ubuf + 1;
+                store_u(ubuf);
+            };
+            auto barrier_u = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+            load_u(0);
+            store_u(0);                                                  // slab 0 -> U[0]
+            if (q_total > 1) {
+                next_load_u();
+                next_store_u();                                          // slab 1 -> U[1]
+            }
+            if (q_total > 2) next_load_u();                              // slab 2 in flight
+            barrier_u();                                                 // barrier(-1)
+            long q = 0;
+            for (; q + 3 < q_total; ++q) {
+                next_store_u();                                          // slab q+2
+                next_load_u();                                           // slab q+3
+                barrier_u();
+            }
+            for (; q < q_total; ++q) {
+                if (q + 2 < q_total) next_store_u();
+                if (q + 3 < q_total) next_load_u();
+                barrier_u();
             }
             return;
         }
@@ -233,16 +260,44 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         store_v(dA, 0);
         if (q_total > 2) next_load(dA);
         barrier();                                                       // barrier(-1)
-        for (long q = 0; q < q_total; q += 2) {
-            // step q (even): slab q+1 sits in dB
-            if (q + 1 < q_total) store_v(dB, 1);
-            if (q + 3 < q_total) next_load(dB);
+        // Steady state without conditions around the loads: the compiler's vmcnt model only counts what is issued on EVERY path, so a
+        // guarded next_load made every store_v wait for the newest batch as well (vmcnt 31..0 instead of 63..32) -- found by
+        // reading the ISA after the s_memtime trace showed store_v still waiting ~2600 cycles.
+        long q = 0;
+        for (; q + 4 < q_total; q += 2) {
+            WTRACE(tid == 256, 1024, q, 0, WNOW());
+            store_v(dB, 1);                                              // slab q+1
+            WTRACE(tid == 256, 1024, q, 1, WNOW());
+            next_load(dB);                                               // slab q+3
+            WTRACE(tid == 256, 1024, q, 2, WNOW());
             barrier();
+            WTRACE(tid == 256, 1024, q, 3, WNOW());
+            WTRACE(tid == 256, 1024, q + 1, 0, WNOW());
+            store_v(dA, 0);                                              // slab q+2
+            WTRACE(tid == 256, 1024, q + 1, 1, WNOW());
+            next_load(dA);                                               // slab q+4
+            WTRACE(tid == 256, 1024, q + 1, 2, WNOW());
+            barrier();
+            WTRACE(tid == 256, 1024, q + 1, 3, WNOW());
+        }
+        for (; q < q_total; q += 2) {                                    // the last steps, guarded
+            // step q (even): slab q+1 sits in dB
+            WTRACE(tid == 256, 1024, q, 0, WNOW());
+            if (q + 1 < q_total) store_v(dB, 1);
+            WTRACE(tid == 256, 1024, q, 1, WNOW());
+            if (q + 3 < q_total) next_load(dB);
+            WTRACE(tid == 256, 1024, q, 2, WNOW());
+            barrier();
+            WTRACE(tid == 256, 1024, q, 3, WNOW());
             if (q + 1 >= q_total) break;
             // step q+1 (odd): slab q+2 sits in dA
+            WTRACE(tid == 256, 1024, q + 1, 0, WNOW());
             if (q + 2 < q_total) store_v(dA, 0);
+            WTRACE(tid == 256, 1024, q + 1, 1, WNOW());
             if (q + 4 < q_total) next_load(dA);
+            WTRACE(tid == 256, 1024, q + 1, 2, WNOW());
             barrier();
+            WTRACE(tid == 256, 1024, q + 1, 3, WNOW());
         }
         return;
     }
@@ -333,6 +388,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             const unsigned ua = ua0 + (unsigned)ub * (WN_U_FLOATS * 4u), vb = vb0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u),
                            vc = vc0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u);
             ub = ub == 2 ? 0 : ub + 1;
+            WTRACE(tid == 0, 2048, slab, 0, WNOW());
             if (pmask) st_pair(ch);
             // fragment reads run two xi steps (8 MFMAs = 256 cycles) ahead of their use
             f32x2 a[3], b0[3], b1[3];
@@ -371,7 +427,9 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            WTRACE(tid == 0, 2048, slab, 1, WNOW());
             asm volatile("s_barrier" ::: "memory");                      // all LDS reads of this slab retired (lgkmcnt(0) above)
+            WTRACE(tid == 0, 2048, slab, 2, WNOW());
         }
         // ---- output transform of this tile into the pending registers (the producers are already staging the next tile)
         {

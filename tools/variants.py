@@ -26,7 +26,9 @@ def main():
     others = [s for s in B.SOURCES if s != src]
     with ThreadPoolExecutor(6) as ex:
         base = list(ex.map(lambda s: obj(s, os.path.join(OUT, s + ".o")), others))
-        var = list(ex.map(lambda v: obj(src, os.path.join(OUT, "%s_%s_%s.o" % (src, macro, v)), ["-D%s=%s" % (macro, v)]), values))
+        # a value may carry further macros: "1+WINO_ABLATE=16" -> -DMACRO=1 -DWINO_ABLATE=16
+        flags = lambda v: ["-D%s=%s" % (macro, v.split("+")[0])] + ["-D" + e for e in v.split("+")[1:]]
+        var = list(ex.map(lambda v: obj(src, os.path.join(OUT, "%s_%s_%s.o" % (src, macro, v)), flags(v)), values))
     for v, o in zip(values, var):
         lib = os.path.join(OUT, "libfaoctasr_%s_%s.so" % (macro, v))
         subprocess.run(FLAGS + ["-shared"] + base + [o, "-o", lib], check=True)

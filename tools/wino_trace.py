@@ -10,10 +10,10 @@ with torch.no_grad():
         y = ops.conv2d(x, w, bias, 1, 1, False, None, 0.2)
 torch.cuda.synchronize()
 t = bias.view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff
-p = t[1024:1152].reshape(32, 4); c = t[2048:2176].reshape(32, 4)
-print("producer: store_v(wait+xform)  issue(DMA+loads)  barrier-wait   total")
-for r in p[:24]:
-    print("   %6d %6d %6d   %6d" % ((r[1]-r[0]) & 0xffffffff, (r[2]-r[1]) & 0xffffffff, (r[3]-r[2]) & 0xffffffff, (r[3]-r[0]) & 0xffffffff))
-print("consumer: mfma-loop  barrier-wait")
-for r in c[:24]:
-    print("   %6d %6d" % ((r[1]-r[0]) & 0xffffffff, (r[2]-r[1]) & 0xffffffff))
+p = t[1024:1152].reshape(32, 4); c = t[2048:2176].reshape(32, 4); u = t[3072:3200].reshape(32, 4)
+d = lambda a, b: int((a - b) & 0xffffffff)
+print("slab | transform wave: store_v  loads  barrier | weights wave: store  loads  barrier | consumer: mfma-loop  barrier  (to next slab start)")
+for i in range(24):
+    nxt = d(c[i + 1][0], c[i][2]) if i + 1 < 32 else 0
+    print("%4d | %6d %6d %6d | %6d %6d %6d | %6d %6d %6d" % (16 + i, d(p[i][1], p[i][0]), d(p[i][2], p[i][1]), d(p[i][3], p[i][2]),
+          d(u[i][1], u[i][0]), d(u[i][2], u[i][1]), d(u[i][3], u[i][2]), d(c[i][1], c[i][0]), d(c[i][2], c[i][1]), nxt))
