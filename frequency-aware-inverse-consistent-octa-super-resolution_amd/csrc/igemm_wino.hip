@@ -134,6 +134,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         //       counts vmcnt exactly (it must wait vmcnt(0) before an LDS store once an LDS-DMA is in flight in the same wave,
         //       which made the prefetch one step deep and left ~3000 cycles of HBM latency exposed per slab: s_memtime trace).
         //   waves 6-7 (WEIGHTS): the transformed-weight slab of slab q+2 into U[(q+2)%3] through registers (see below).
+        __builtin_amdgcn_s_setprio(3);                                   // staging ahead of the consumers' MFMA stream in the issue arbiter
         const int stid = tid & 255;
         const int nslab_u = nchunks;
         const long my_tiles = (total_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
