@@ -247,3 +247,26 @@ def test_graph_captured_step_matches_eager_and_golden(fa, O):
     # replay histories hold the same images (up to step-to-step rounding drift)
     assert len(ts.fake_A_buffer.data) == len(eager.fake_A_buffer.data)
     close(ts.fake_A_buffer.data[0], eager.fake_A_buffer.data[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_train_step_bench_workload_vs_oracle(fa, O):
+    """BASELINE configs[1] at FULL size -- 256x256, batch 8, the exact shapes bench.py times (Winograd on the 3x3 layers, split-K
+    on the narrow maps) -- against the CPU oracle on the same seeded inputs: step-0 losses to 1e-3, gradient norms to 2e-3,
+    PSNR of the cycle reconstruction to 1e-3; and the same step with precision="f32_direct" (no Winograd) agrees as well."""
+    random.seed(1234)
+    torch.set_num_threads(host_threads())
+    a, b = O.synthetic_batch(8, 256, seed=4321)
+    S = O.StepOracle(seed=0)
+    Lo = S.train_step(a, b, keep=True)
+    go = S.grad_norms()
+    psnr_o = float(O.psnr(Lo["tensors"]["recovered_A"], a))
+    for prec in ("f32", "f32_direct"):
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], precision=prec)
+        L = ts.step(a.cuda(), b.cuda(), sync=True, keep=True)
+        _check_step(L, Lo, 0)
+        gn = ts.grad_norms()
+        for k in gn:
+            assert gn[k] == pytest.approx(go[k], rel=2e-3), (prec, k, gn[k], go[k])
+        assert float(fa.psnr(L["tensors"]["recovered_A"], a.cuda())) == pytest.approx(psnr_o, rel=1e-3)
