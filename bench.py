@@ -231,7 +231,7 @@ def main():
         extra["conv_ms_per_step"] = round((ms + ms2) / nroof, 2)
         extra["conv_tflop_per_step"] = round((fl + fl2) / nroof / 1e12, 3)
     # secondary measurement (never the headline): the same step with the opt-in bf16x3 contraction
-    if rank == 0 and world == 1 and args.precision == "f32" and not args.no_alt:
+    if rank == 0 and not distributed and args.precision == "f32" and not args.no_alt:
         ts.precision = "bf16x3"
         for _ in range(2):
             ts.step(real_A, real_B)
@@ -247,7 +247,7 @@ def main():
                                                   "wgrad and everything else f32",
                                          "parity": "step-0 losses within 1e-4, gradient norms within 2.3e-4 of the f32 path (tests/test_gpu_step.py)"}
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
-    if rank == 0 and world == 1 and not args.no_graph:
+    if rank == 0 and not distributed and not args.no_graph:
         gs = faoctasr.GraphedTrainStep(ts, real_A, real_B)
         for _ in range(2):
             gs.step(real_A, real_B)
