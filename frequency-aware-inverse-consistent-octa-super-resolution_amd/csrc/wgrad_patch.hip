@@ -11,6 +11,8 @@
 // per-lane constant base plus a wave-uniform pixel offset: no im2col arithmetic in the MFMA loop, and dY / X are read
 // about once per column slab instead of once per 64 columns.  Fragment reads are software pipelined with hand-counted
 // waits (see igemm_patch.hip).  Partial sums go to the gradient arena with fp32 atomics (split over pixel ranges).
+#include <type_traits>
+
 #include "common.h"
 #include "igemm_geom.h"
 
@@ -33,7 +35,13 @@ __device__ __forceinline__ int reflect_idx_w(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
-__device__ __forceinline__ void ds_read_w(float& dst, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr)); }
+template <int I, int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wg_static_for<I + 1, N>(f);
+    }
+}
 
 constexpr int WG_TH = 2, WG_PIX = WG_TH * 32, WG_LDY = WG_PIX + 1, WG_MT = 64;
 constexpr int WG_NPV = 20;                    // patch elements staged per thread
@@ -208,52 +216,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
         const int cur = (int)(tile - tile0) & 1;
         if (tile + 1 < tile1) load_tile(tile + 1);
         // A fragment: D[m = l31 (+32)][pixel 2s + lh]; B fragment: P[bbase + pixel offset]
-        unsigned Aa = lds0 + 4u * (unsigned)(cur * WG_MT * WG_LDY + (wm * 32 + l31) * WG_LDY + lh);
-        unsigned Ba[NI];
+        // Addresses inside the tile are immediates of the LDS reads: pixel pair s of a row sits 8 s bytes on (stride 1: the
+        // launcher sends nothing else here), the second pixel row PW floats further -- no address arithmetic between the MFMAs
+        // (vector instructions are not hidden behind f32 MFMAs on this chip: DESIGN.md 4.1a).
+        const unsigned Aa = lds0 + 4u * (unsigned)(cur * WG_MT * WG_LDY + (wm * 32 + l31) * WG_LDY + lh);
+        unsigned Ba[NI], Bb[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Ba[ni] = lds0 + 4u * (unsigned)(2 * WG_MT * WG_LDY + cur * npatch + bbase[ni]);
-        const unsigned b_step = 8u * (unsigned)S, b_rowfix = 4u * (unsigned)(S * PW - 32 * S);
+        for (int ni = 0; ni < NI; ++ni) {
+            Ba[ni] = lds0 + 4u * (unsigned)(2 * WG_MT * WG_LDY + cur * npatch + bbase[ni]);
+            Bb[ni] = Ba[ni] + 4u * (unsigned)PW;
+        }
         float a0[MI], b0[NI], a1[MI], b1[NI];
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        auto rd = [&](float (&a)[MI], float (&b)[NI]) {
-            ds_read_w(a[0], Aa);
+        auto rd = [&](auto sc, float (&a)[MI], float (&b)[NI]) {
+            constexpr int st = decltype(sc)::value;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[0]) : "v"(Aa), "n"(8 * st));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) ds_read_w(b[ni], Ba[ni]);
+            for (int ni = 0; ni < NI; ++ni) {
+                const unsigned ba = st < 16 ? Ba[ni] : Bb[ni];
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[ni]) : "v"(ba), "n"(8 * (st & 15)));
+            }
         };
-        auto adv = [&](int s_next) {                                     // s_next = index of the step being fetched
-            Aa += 8u;
-            const unsigned fix = ((s_next & 15) == 0) ? b_rowfix : 0u;   // first pixel pair of the next row
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) Ba[ni] += b_step + fix;
+        auto wait_set = [&](float (&a)[MI], float (&b)[NI], auto morec) {
+            constexpr bool more = decltype(morec)::value;                // a younger set of 1 + NI reads is in flight
+            if constexpr (!more) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]));
+            else if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+            else if constexpr (NI == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+            else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[0]), "+v"(b[0]), "+v"(b[1]));
+            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[0]), "+v"(b[0]));
         };
-        rd(a0, b0);
-        for (int s = 0; s < WG_PIX / 2; s += 2) {
-            adv(s + 1);
-            rd(a1, b1);
-            if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]));
-            else if constexpr (NI == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]));
-            else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0[0]), "+v"(b0[0]), "+v"(b0[1]));
-            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a0[0]), "+v"(b0[0]));
+        rd(std::integral_constant<int, 0>{}, a0, b0);
+        wg_static_for<0, WG_PIX / 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            rd(std::integral_constant<int, 2 * i + 1>{}, a1, b1);
+            wait_set(a0, b0, std::true_type{});
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            adv(s + 2);
-            rd(a0, b0);                                                   // the last one runs past the tile: never used
-            if constexpr (NI == 4) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]));
-            else if constexpr (NI == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]));
-            else if constexpr (NI == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a1[0]), "+v"(b1[0]), "+v"(b1[1]));
-            else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1[0]), "+v"(b1[0]));
+            if constexpr (2 * i + 2 < WG_PIX / 2) {
+                rd(std::integral_constant<int, 2 * i + 2>{}, a0, b0);
+                wait_set(a1, b1, std::true_type{});
+            } else {
+                wait_set(a1, b1, std::false_type{});
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // retire the run-past reads
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tile + 1 < tile1) store_tile(cur ^ 1);
         __syncthreads();
     }
