@@ -105,11 +105,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     // offset relative to the tile origin is tile-invariant, so it is computed once (prel / drel0) and the tile origin moves into
     // the buffer descriptors' base addresses.  Vector instructions are not hidden behind f32 MFMAs on this chip, so
     // the ~500 address instructions per tile and thread of the general path were ~20 % of this kernel's time.
+    // One tile column spanning the whole map (32-wide maps): every tile has the same left / right padding columns, so those are
+    // tile-invariant too and are folded into prel as permanently out-of-range elements.
+    const bool one_col = g.tiles_x == 1 && g.OW == 32 && !g.reflect;
     unsigned prel[WG_NPV];
 #pragma unroll
     for (int i = 0; i < WG_NPV; ++i) {
         const int d = pdec[i];
-        prel[i] = d >= 0 ? 4u * (unsigned)((d >> 16) * (int)ihw + ((d >> 8) & 0xff) * g.IW + (d & 0xff)) : OOB;
+        const int ixs = (d & 0xff) - g.pad;                              // input column when the tile starts at x0 = 0
+        const bool colok = !one_col || (unsigned)ixs < (unsigned)g.IW;
+        prel[i] = (d >= 0 && colok) ? 4u * (unsigned)((d >> 16) * (int)ihw + ((d >> 8) & 0xff) * g.IW + (d & 0xff)) : OOB;
     }
     const unsigned drel0 = 4u * (unsigned)((tid >> 6) * (int)ohw + ((tid & 63) >> 5) * g.OW + (tid & 31));   // + i * 4 rows of m
 
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
         const long dy_bytes = (long)(g.M - m0) * ohw * 4;
         {
             const int iy0f = y0 * S - g.pad, ix0f = x0 * S - g.pad;
-            const bool interior = iy0f >= 0 && iy0f + PH <= g.IH && ix0f >= 0 && ix0f + PW <= g.IW && y0 + WG_TH <= g.OH && x0 + 32 <= g.OW &&
-                                  m0 + WG_MT <= g.M;
+            const bool xin = one_col || (ix0f >= 0 && ix0f + PW <= g.IW && x0 + 32 <= g.OW);
+            const bool interior = iy0f >= 0 && iy0f + PH <= g.IH && xin && y0 + WG_TH <= g.OH && m0 + WG_MT <= g.M;
             if (interior) {
                 const long dshift = (long)y0 * g.OW + x0;
                 const long db = dy_bytes - dshift * 4;
