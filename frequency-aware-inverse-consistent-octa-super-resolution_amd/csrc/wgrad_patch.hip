@@ -48,7 +48,7 @@ constexpr int WG_NPV = 20;                    // patch elements staged per threa
 
 // 256 threads = 4 waves as 2 (rows m) x 2 (columns): a wave owns 32 rows x NI*32 columns, so every SIMD of the CU hosts
 // exactly one wave of each resident block (3-wave blocks left two SIMDs doubly loaded and ran ~2x slower).
-template <int NI>
+template <int NI, int S>
 __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dw, const WgradGeom g) {
     constexpr int NT = 256, CT = 2 * NI * 32, MI = 1;
@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     int c_hi = (col0 + CT - 1) / T;
     c_hi = c_hi < g.C ? c_hi : g.C - 1;
     const int NCH = c_hi - c_lo + 1;
-    const int S = g.S;
     const int PH = (WG_TH - 1) * S + g.KH, PW = 31 * S + g.KW, PHW = PH * PW;
     const int npatch = NCH * PHW;
     const int ndy = WG_MT * WG_PIX;
@@ -221,15 +220,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
         const int cur = (int)(tile - tile0) & 1;
         if (tile + 1 < tile1) load_tile(tile + 1);
         // A fragment: D[m = l31 (+32)][pixel 2s + lh]; B fragment: P[bbase + pixel offset]
-        // Addresses inside the tile are immediates of the LDS reads: pixel pair s of a row sits 8 s bytes on (stride 1: the
-        // launcher sends nothing else here), the second pixel row PW floats further -- no address arithmetic between the MFMAs
+        // Addresses inside the tile are immediates of the LDS reads: pixel pair s of a row sits 8 S s bytes on, the second pixel
+        // row S * PW floats further -- no address arithmetic between the MFMAs
         // (vector instructions are not hidden behind f32 MFMAs on this chip: DESIGN.md 4.1a).
         const unsigned Aa = lds0 + 4u * (unsigned)(cur * WG_MT * WG_LDY + (wm * 32 + l31) * WG_LDY + lh);
         unsigned Ba[NI], Bb[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             Ba[ni] = lds0 + 4u * (unsigned)(2 * WG_MT * WG_LDY + cur * npatch + bbase[ni]);
-            Bb[ni] = Ba[ni] + 4u * (unsigned)PW;
+            Bb[ni] = Ba[ni] + 4u * (unsigned)(S * PW);
         }
         float a0[MI], b0[NI], a1[MI], b1[NI];
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const unsigned ba = st < 16 ? Ba[ni] : Bb[ni];
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[ni]) : "v"(ba), "n"(8 * (st & 15)));
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[ni]) : "v"(ba), "n"(8 * S * (st & 15)));
             }
         };
         auto wait_set = [&](float (&a)[MI], float (&b)[NI], auto morec) {
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     }
 }
 
-template <int NI>
+template <int NI, int S>
 static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hipStream_t s) {
     constexpr int CT = 2 * NI * 32, NT = 256;
     const int T = g.KH * g.KW;
@@ -315,7 +314,7 @@ static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hip
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     slices = (ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
-    auto k = wgrad_patch_kernel<NI>;
+    auto k = wgrad_patch_kernel<NI, S>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3(gx, gy, (unsigned)slices), dim3(NT), lds, s, x, dy, dw, g);
     return true;
@@ -326,7 +325,8 @@ static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hip
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
     // stride-2 layers (large patches, small slabs) measured faster on the flat kernel
-    if (OW < 24 || stride != 1 || KH > 15 || KW > 15 || C * KH * KW < 64) return 0;
+    static const int s2 = getenv("FAOCTASR_WGRAD_S2") ? atoi(getenv("FAOCTASR_WGRAD_S2")) : 1;
+    if (OW < 24 || (stride != 1 && !(stride == 2 && s2)) || KH > 15 || KW > 15 || C * KH * KW < 64) return 0;
     WgradGeom g;
     g.N = N; g.C = C; g.IH = IH; g.IW = IW; g.M = M; g.OH = OH; g.OW = OW; g.S = stride; g.pad = pad; g.KH = KH; g.KW = KW;
     g.reflect = reflect; g.wsm = wsm; g.wsc = wsc; g.ncols = C * KH * KW;
@@ -346,10 +346,17 @@ int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C,
     }
     bool ok = false;
     for (int ni = best; ni >= 1 && !ok; --ni) {
-        if (ni == 4) ok = wg_try<4>(x, dy, dw, g, s);
-        else if (ni == 3) ok = wg_try<3>(x, dy, dw, g, s);
-        else if (ni == 2) ok = wg_try<2>(x, dy, dw, g, s);
-        else ok = wg_try<1>(x, dy, dw, g, s);
+        if (stride == 1) {
+            if (ni == 4) ok = wg_try<4, 1>(x, dy, dw, g, s);
+            else if (ni == 3) ok = wg_try<3, 1>(x, dy, dw, g, s);
+            else if (ni == 2) ok = wg_try<2, 1>(x, dy, dw, g, s);
+            else ok = wg_try<1, 1>(x, dy, dw, g, s);
+        } else {
+            if (ni == 4) ok = wg_try<4, 2>(x, dy, dw, g, s);
+            else if (ni == 3) ok = wg_try<3, 2>(x, dy, dw, g, s);
+            else if (ni == 2) ok = wg_try<2, 2>(x, dy, dw, g, s);
+            else ok = wg_try<1, 2>(x, dy, dw, g, s);
+        }
     }
     if (!ok) return 0;
     const int rc = check_launch("wgrad_patch");
