@@ -21,7 +21,8 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(HERE, "csrc", s) for s in SOURCES if os.path.exists(os.path.join(HERE, "csrc", s))]
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+    extra = os.environ.get("FAOCTASR_HIPCC_FLAGS", "").split()
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"] + extra + ["-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(HERE, "csrc")] + srcs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
