@@ -12,6 +12,8 @@
 //
 // GEMM per phase (see igemm.hip for the phase decomposition of transposed convolutions):
 //   Y[m][(n,a,b)] = sum_{t,c} Wp[(t,c)][m] * X[n][c][a*SI + oy_t][b*SI + ox_t]
+#include <type_traits>
+
 #include "common.h"
 #include "igemm_geom.h"
 
@@ -32,6 +34,21 @@ __device__ __forceinline__ int reflect_idx_p(int i, int n) {
 __device__ __forceinline__ void ds_read_f32(float& dst, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr)); }
 __device__ __forceinline__ void ds_read_f32_o128(float& dst, unsigned addr) {
     asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(dst) : "v"(addr));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void pk_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pk_static_for<I + 1, N>(f);
+    }
+}
+// fragment reads whose offsets are immediates of the instruction (dense-grid specialisation: no address arithmetic at all)
+template <int MI, int NI, int AOFF, int BOFF, int BROW>
+__device__ __forceinline__ void read_frags_imm(float (&a)[MI], float (&b)[NI], unsigned abase, unsigned bbase) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[0]) : "v"(abase), "n"(AOFF));
+    if constexpr (MI == 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[1]) : "v"(abase), "n"(AOFF + 128));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[0]) : "v"(bbase), "n"(BOFF));
+    if constexpr (NI == 2) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(b[1]) : "v"(bbase), "n"(BOFF + BROW));
 }
 template <int MI, int NI>
 __device__ __forceinline__ void read_frags(float (&a)[MI], float (&b)[NI], unsigned aaddr, unsigned baddr, unsigned brow_bytes) {
@@ -75,7 +92,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <int WM, int WN, int MI, int NI, int SI>
+template <int WM, int WN, int MI, int NI, int SI, int DENSE = 0>
 __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           const PatchGeom g, const int ksplit) {
@@ -212,6 +229,49 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
         unsigned Pa = Pc + 4u * (unsigned)__builtin_amdgcn_readlane(tapv, 0);
         const unsigned brow = 4u * (unsigned)(SI * PW), a_step = 8u * MT, p_step = 8u * (unsigned)PHW;
         float a0[MI], b0[NI], a1[MI], b1[NI];          // two named fragment sets (static indexing, no copies)
+        if constexpr (DENSE != 0) {
+            // Dense KW x KW stride-1 tap grid with one channel pair per chunk (the 7x7 layers): tap t's patch offset and weight row
+            // are compile-time, so every fragment read carries its address as an immediate and the k-loop is reads + MFMAs only.
+            // (Vector instructions are not hidden behind f32 MFMAs on this chip: DESIGN.md 4.1a.)  DENSE > 0: taps in ascending
+            // (ky, kx) order (forward); DENSE < 0: descending (the input gradient of a stride-1 convolution).
+            constexpr int KW = DENSE > 0 ? DENSE : -DENSE, TT = KW * KW, PWc = 31 * SI + KW, BROW = 4 * SI * PWc;
+            const unsigned Ab = lds0 + 4u * (unsigned)(cur * a_floats + a_lane);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            auto boff = [](int tt) constexpr { return DENSE > 0 ? 4 * ((tt / KW) * PWc + tt % KW) : 4 * ((KW - 1 - tt / KW) * PWc + (KW - 1 - tt % KW)); };
+            read_frags_imm<MI, NI, 0, boff(0), BROW>(a0, b0, Ab, Pc);
+            pk_static_for<0, (TT + 1) / 2>([&](auto ic) {
+                constexpr int tt = 2 * decltype(ic)::value;
+                if constexpr (tt + 1 < TT) {
+                    read_frags_imm<MI, NI, (tt + 1) * 8 * MT, boff(tt + 1), BROW>(a1, b1, Ab, Pc);
+                    wait_frags_keep_next<MI, NI>(a0, b0);
+                } else {
+                    wait_frags_all<MI, NI>(a0, b0);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (tt + 1 < TT) {
+                    if constexpr (tt + 2 < TT) {
+                        read_frags_imm<MI, NI, (tt + 2) * 8 * MT, boff(tt + 2), BROW>(a0, b0, Ab, Pc);
+                        wait_frags_keep_next<MI, NI>(a1, b1);
+                    } else {
+                        wait_frags_all<MI, NI>(a1, b1);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mi], b1[ni], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if (ch + 1 < ch1) store_patch(cur ^ 1, ch + 1);
+            __syncthreads();
+            continue;
+        }
         int t = 0, cp = 0;
         auto advance = [&]() {                           // branch-free: keeps the loop body straight-line
             cp += 2;
@@ -438,7 +498,32 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
     }
     dim3 grid((unsigned)mx, (g.M + MT - 1) / MT, g.nphase * ksplit);
     const size_t lds = patch_lds_bytes<WM, WN, MI, NI>(g, g.SI);
-    if (g.SI == 1) {
+    // dense 7x7 stride-1 grid, one channel pair per chunk: the specialisation with compile-time taps (config B only)
+    int dense = 0;
+    if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
+        if (g.SI == 1 && g.nphase == 1 && g.t0[1] - g.t0[0] == 49 && g.kc[0] == 2 && g.span_x[0] == 6 && g.span_y[0] == 6) {
+            bool fwd = true, rev = true;
+            for (int t = 0; t < 49; ++t) {
+                const int ty = g.taps[t] & 0xff, tx = (g.taps[t] >> 8) & 0xff;
+                fwd = fwd && ty == t / 7 && tx == t % 7;
+                rev = rev && ty == 6 - t / 7 && tx == 6 - t % 7;
+            }
+            dense = fwd ? 7 : rev ? -7 : 0;
+        }
+    }
+    if (dense == 7) {
+        if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
+            auto k = igemm_patch_kernel<WM, WN, MI, NI, 1, 7>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
+        }
+    } else if (dense == -7) {
+        if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
+            auto k = igemm_patch_kernel<WM, WN, MI, NI, 1, -7>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
+        }
+    } else if (g.SI == 1) {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
