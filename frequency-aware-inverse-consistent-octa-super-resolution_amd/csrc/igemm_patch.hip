@@ -12,6 +12,8 @@
 //
 // GEMM per phase (see igemm.hip for the phase decomposition of transposed convolutions):
 //   Y[m][(n,a,b)] = sum_{t,c} Wp[(t,c)][m] * X[n][c][a*SI + oy_t][b*SI + ox_t]
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -92,7 +94,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
-template <int WM, int WN, int MI, int NI, int SI, int DENSE = 0>
+template <int WM, int WN, int MI, int NI, int SI, int DENSE = 0, int KCS = 2>
 __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           const PatchGeom g, const int ksplit) {
@@ -230,19 +232,25 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
         const unsigned brow = 4u * (unsigned)(SI * PW), a_step = 8u * MT, p_step = 8u * (unsigned)PHW;
         float a0[MI], b0[NI], a1[MI], b1[NI];          // two named fragment sets (static indexing, no copies)
         if constexpr (DENSE != 0) {
-            // Dense KW x KW stride-1 tap grid with one channel pair per chunk (the 7x7 layers): tap t's patch offset and weight row
-            // are compile-time, so every fragment read carries its address as an immediate and the k-loop is reads + MFMAs only.
-            // (Vector instructions are not hidden behind f32 MFMAs on this chip: DESIGN.md 4.1a.)  DENSE > 0: taps in ascending
-            // (ky, kx) order (forward); DENSE < 0: descending (the input gradient of a stride-1 convolution).
-            constexpr int KW = DENSE > 0 ? DENSE : -DENSE, TT = KW * KW, PWc = 31 * SI + KW, BROW = 4 * SI * PWc;
+            // Dense KW x KW tap grid with a compile-time chunk of KCS channels (the 7x7 layers, the 4x4 stride-2 layers, the 2x2
+            // phases of the 4x4 transposed convolution): step s = (tap, channel pair) has a compile-time patch offset and weight
+            // row, so every fragment read carries its address as an immediate and the k-loop is reads + MFMAs only.  (Vector
+            // instructions are not hidden behind f32 MFMAs on this chip: DESIGN.md 4.1a.)  DENSE > 0: taps in ascending (ky, kx)
+            // order; DENSE < 0: descending (input gradient of a stride-1 convolution, phases of a transposed one).
+            constexpr int KW = DENSE > 0 ? DENSE : -DENSE, CP = KCS / 2, NS = KW * KW * CP;
+            constexpr int PWc = 31 * SI + KW, PHc = (TH - 1) * SI + KW, BROW = 4 * SI * PWc;
             const unsigned Ab = lds0 + 4u * (unsigned)(cur * a_floats + a_lane);
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            auto boff = [](int tt) constexpr { return DENSE > 0 ? 4 * ((tt / KW) * PWc + tt % KW) : 4 * ((KW - 1 - tt / KW) * PWc + (KW - 1 - tt % KW)); };
+            auto boff = [](int st) constexpr {
+                const int tt = st / CP, cq = st % CP;
+                const int tap = DENSE > 0 ? (tt / KW) * PWc + tt % KW : (KW - 1 - tt / KW) * PWc + (KW - 1 - tt % KW);
+                return 4 * (tap + 2 * cq * PHc * PWc);
+            };
             read_frags_imm<MI, NI, 0, boff(0), BROW>(a0, b0, Ab, Pc);
-            pk_static_for<0, (TT + 1) / 2>([&](auto ic) {
-                constexpr int tt = 2 * decltype(ic)::value;
-                if constexpr (tt + 1 < TT) {
-                    read_frags_imm<MI, NI, (tt + 1) * 8 * MT, boff(tt + 1), BROW>(a1, b1, Ab, Pc);
+            pk_static_for<0, (NS + 1) / 2>([&](auto ic) {
+                constexpr int st = 2 * decltype(ic)::value;
+                if constexpr (st + 1 < NS) {
+                    read_frags_imm<MI, NI, (st + 1) * 8 * MT, boff(st + 1), BROW>(a1, b1, Ab, Pc);
                     wait_frags_keep_next<MI, NI>(a0, b0);
                 } else {
                     wait_frags_all<MI, NI>(a0, b0);
@@ -253,9 +261,9 @@ __global__ __launch_bounds__(256) void igemm_patch_kernel(const float* __restric
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mi], b0[ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (tt + 1 < TT) {
-                    if constexpr (tt + 2 < TT) {
-                        read_frags_imm<MI, NI, (tt + 2) * 8 * MT, boff(tt + 2), BROW>(a0, b0, Ab, Pc);
+                if constexpr (st + 1 < NS) {
+                    if constexpr (st + 2 < NS) {
+                        read_frags_imm<MI, NI, (st + 2) * 8 * MT, boff(st + 2), BROW>(a0, b0, Ab, Pc);
                         wait_frags_keep_next<MI, NI>(a1, b1);
                     } else {
                         wait_frags_all<MI, NI>(a1, b1);
@@ -498,31 +506,50 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
     }
     dim3 grid((unsigned)mx, (g.M + MT - 1) / MT, g.nphase * ksplit);
     const size_t lds = patch_lds_bytes<WM, WN, MI, NI>(g, g.SI);
-    // dense 7x7 stride-1 grid, one channel pair per chunk: the specialisation with compile-time taps (config B only)
-    int dense = 0;
-    if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
-        if (g.SI == 1 && g.nphase == 1 && g.t0[1] - g.t0[0] == 49 && g.kc[0] == 2 && g.span_x[0] == 6 && g.span_y[0] == 6) {
-            bool fwd = true, rev = true;
-            for (int t = 0; t < 49; ++t) {
-                const int ty = g.taps[t] & 0xff, tx = (g.taps[t] >> 8) & 0xff;
-                fwd = fwd && ty == t / 7 && tx == t % 7;
-                rev = rev && ty == 6 - t / 7 && tx == 6 - t % 7;
+    // dense tap grids with a known chunk size take the specialisations with compile-time taps
+    int dkw = 0, dord = 0;                                              // grid width, +1 ascending / -1 descending
+    {
+        const int T0 = g.t0[1] - g.t0[0];
+        int kw = 0;
+        while (kw * kw < T0) ++kw;
+        bool ok = kw * kw == T0 && kw >= 2;
+        bool asc = true, desc = true;
+        for (int p = 0; ok && p < g.nphase; ++p) {
+            ok = g.t0[p + 1] - g.t0[p] == T0 && g.span_x[p] == kw - 1 && g.span_y[p] == kw - 1 && g.kc[p] == g.kc[0];
+            for (int t = 0; ok && t < T0; ++t) {
+                const int ty = g.taps[g.t0[p] + t] & 0xff, tx = (g.taps[g.t0[p] + t] >> 8) & 0xff;
+                asc = asc && ty == t / kw && tx == t % kw;
+                desc = desc && ty == kw - 1 - t / kw && tx == kw - 1 - t % kw;
             }
-            dense = fwd ? 7 : rev ? -7 : 0;
+        }
+        if (ok && (asc || desc)) { dkw = kw; dord = asc ? 1 : -1; }
+    }
+    if (getenv("FAOCTASR_DEBUG_DENSE"))
+        fprintf(stderr, "patch cfg <%d,%d,%d,%d> SI=%d nphase=%d T0=%d kc=%d span=(%d,%d) dense kw=%d ord=%d\n", WM, WN, MI, NI, g.SI, g.nphase,
+                g.t0[1] - g.t0[0], g.kc[0], g.span_y[0], g.span_x[0], dkw, dord);
+    auto launch = [&](auto k) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
+    };
+    bool done = false;
+    if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {          // config B
+        if (g.SI == 1 && dkw == 7 && g.kc[0] == 2) {
+            if (dord > 0) launch(igemm_patch_kernel<WM, WN, MI, NI, 1, 7, 2>);
+            else launch(igemm_patch_kernel<WM, WN, MI, NI, 1, -7, 2>);
+            done = true;
+        } else if (g.SI == 1 && dkw == 2 && g.kc[0] == 16) {            // the four 2x2 phases of ConvTranspose2d(4, stride 2)
+            if (dord > 0) launch(igemm_patch_kernel<WM, WN, MI, NI, 1, 2, 16>);
+            else launch(igemm_patch_kernel<WM, WN, MI, NI, 1, -2, 16>);
+            done = true;
         }
     }
-    if (dense == 7) {
-        if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
-            auto k = igemm_patch_kernel<WM, WN, MI, NI, 1, 7>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
+    if constexpr (WM == 2 && WN == 2 && MI == 2 && NI == 2) {          // config A
+        if (g.SI == 2 && dkw == 4 && dord > 0 && g.kc[0] == 2) {        // Conv2d(4, stride 2): discriminator stages, convT input gradient
+            launch(igemm_patch_kernel<WM, WN, MI, NI, 2, 4, 2>);
+            done = true;
         }
-    } else if (dense == -7) {
-        if constexpr (WM == 1 && WN == 4 && MI == 2 && NI == 2) {
-            auto k = igemm_patch_kernel<WM, WN, MI, NI, 1, -7>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
-        }
+    }
+    if (done) {
     } else if (g.SI == 1) {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
