@@ -547,6 +547,13 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
         if (g.SI == 2 && dkw == 4 && dord > 0 && g.kc[0] == 2) {        // Conv2d(4, stride 2): discriminator stages, convT input gradient
             launch(igemm_patch_kernel<WM, WN, MI, NI, 2, 4, 2>);
             done = true;
+        } else if (g.SI == 2 && dkw == 3 && dord > 0 && g.kc[0] == 4) { // Conv2d(3, stride 2): the generator's down-sampling stages
+            launch(igemm_patch_kernel<WM, WN, MI, NI, 2, 3, 4>);
+            done = true;
+        } else if (g.SI == 1 && dkw == 2 && g.kc[0] == 8) {             // 2x2 phases: input gradient of Conv2d(4, stride 2) with > 64 channels
+            if (dord > 0) launch(igemm_patch_kernel<WM, WN, MI, NI, 1, 2, 8>);
+            else launch(igemm_patch_kernel<WM, WN, MI, NI, 1, -2, 8>);
+            done = true;
         }
     }
     if (done) {
