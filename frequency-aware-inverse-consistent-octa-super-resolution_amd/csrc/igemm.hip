@@ -87,7 +87,49 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const float* __restri
     float ra[NA], rb[8];
     __syncthreads();   // taps_s visible
 
+    // When the tap count divides the chunk (the 4x4 layers: T = 16 forward, 4 per phase in the input gradient) a thread's
+    // element of every chunk is the same (tap, channel-within-chunk): decode it ONCE -- the (c, t) split, the tap lookup, padding
+    // test and in-plane offset cost ~30 vector instructions per element and chunk otherwise, and vector instructions are not
+    // hidden behind f32 MFMAs on this chip.  Per chunk what is left is base + channel * stride.
+    const bool fixed_taps = T > 0 && (KC % T) == 0 && (kbeg % T) == 0;
+    const int akk = tid & 15;                                           // A element: (row tid>>4 + 16 i, k offset akk)
+    int a_cl = 0;
+    long a_off = 0;
+    int b_cl[8];
+    long b_off[8];                                                      // in-plane offset of B element i, -1 = padding
+    if (fixed_taps) {
+        a_cl = akk / T;
+        a_off = taps_s[t0 + akk % T] >> 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kk = rg + 2 * i;
+            b_cl[i] = kk / T;
+            const int tp = taps_s[t0 + kk % T];
+            int iy = iy0 + (tp & 0xff) - 64, ix = ix0 + ((tp >> 8) & 0xff) - 64;
+            if (g.reflect) {
+                iy = reflect_idx(iy, IH);
+                ix = reflect_idx(ix, IW);
+            }
+            b_off[i] = (jv && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) ? (long)iy * IW + ix : -1;
+        }
+    }
+
     auto load_chunk = [&](int k0) {
+        if (fixed_taps) {
+            const int cb = k0 / T;                                      // uniform: first channel of the chunk
+            const int ca = cb + a_cl;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int m = m0 + (tid >> 4) + 16 * i;
+                ra[i] = (m < g.M && ca < g.C && k0 + akk < K) ? w[(long)m * g.wsm + (long)ca * g.wsc + a_off] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cb + b_cl[i];
+                rb[i] = (b_off[i] >= 0 && c < g.C && k0 + rg + 2 * i < K) ? xin[(long)c * chw + b_off[i]] : 0.f;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tid + 256 * i;
