@@ -107,15 +107,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     // One tile column spanning the whole map (32-wide maps): every tile has the same left / right padding columns, so those are
     // tile-invariant too and are folded into prel as permanently out-of-range elements.
     const bool one_col = g.tiles_x == 1 && g.OW == 32 && !g.reflect;
-    unsigned prel[WG_NPV];
+    constexpr bool USE_PREL = S != 1;                                   // stride 1 takes the wide path below instead (registers)
+    unsigned prel[USE_PREL ? WG_NPV : 1];
 #pragma unroll
-    for (int i = 0; i < WG_NPV; ++i) {
+    for (int i = 0; i < (USE_PREL ? WG_NPV : 1); ++i) {
         const int d = pdec[i];
         const int ixs = (d & 0xff) - g.pad;                              // input column when the tile starts at x0 = 0
         const bool colok = !one_col || (unsigned)ixs < (unsigned)g.IW;
         prel[i] = (d >= 0 && colok) ? 4u * (unsigned)((d >> 16) * (int)ihw + ((d >> 8) & 0xff) * g.IW + (d & 0xff)) : OOB;
     }
     const unsigned drel0 = 4u * (unsigned)((tid >> 6) * (int)ohw + ((tid & 63) >> 5) * g.OW + (tid & 31));   // + i * 4 rows of m
+
+    // Wide fast path (stride 1): the texture path sustains only one wave-instruction per ~50 cycles here (s_memtime trace: 2000
+    // cycles to issue a tile's 36 dword loads, a third of the MFMA time), so interior tiles fetch 16-byte pieces instead -- dY
+    // rows as 4 float4 per thread, the patch as aligned 4-column chunks [x0 - 4 + 4 ck, +4) of each (channel, row), at most 5 per
+    // thread -- and scatter them into the same LDS layout.  9 loads per thread and tile instead of 36.
+    constexpr int WCH = WG_NPV / 4;                                      // chunks per thread
+    const bool wide_ok = S == 1 && (g.IW & 3) == 0 && (ihw & 3) == 0 && (g.OW & 3) == 0 && (ohw & 3) == 0 && g.pad <= 4 && PW - g.pad <= 36 &&
+                         NCH * PH * 10 <= NT * WCH;
+    int w_lds[WCH], w_rel[WCH], w_ck[WCH];                               // LDS float offset of the chunk's first column, global float offset, chunk index
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int item = tid + NT * i;
+        const int c = item / (PH * 10), r = item - c * (PH * 10), row = r / 10, ck = r - row * 10;
+        const bool use = wide_ok && item < NCH * PH * 10;
+        w_ck[i] = use ? ck : -1;
+        w_lds[i] = c * PHW + row * PW + 4 * ck - (4 - g.pad);
+        w_rel[i] = c * (int)ihw + row * g.IW + 4 * ck;
+    }
+    bool loaded_wide = false;
 
     auto tile_coords = [&](long tile, int& n, int& y0, int& x0) {
         n = (int)(tile / g.tiles_per_img);
@@ -133,7 +153,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
             const int iy0f = y0 * S - g.pad, ix0f = x0 * S - g.pad;
             const bool xin = one_col || (ix0f >= 0 && ix0f + PW <= g.IW && x0 + 32 <= g.OW);
             const bool interior = iy0f >= 0 && iy0f + PH <= g.IH && xin && y0 + WG_TH <= g.OH && m0 + WG_MT <= g.M;
-            if (interior) {
+            loaded_wide = false;
+            const bool xwide = g.reflect ? (ix0f >= 0 && ix0f + PW <= g.IW) : true;      // zero padding = whole chunks outside the row
+            if (wide_ok && iy0f >= 0 && iy0f + PH <= g.IH && xwide && y0 + WG_TH <= g.OH && x0 + 32 <= g.OW && m0 + WG_MT <= g.M) {
+                loaded_wide = true;
+                const float* dbase = dyp + (long)y0 * g.OW + x0;
+#pragma unroll
+                for (int i = 0; i < NDY / 4; ++i) {
+                    const int e4 = tid + NT * i;
+                    const float4 v = *reinterpret_cast<const float4*>(dbase + (long)(e4 >> 4) * ohw + ((e4 & 15) >> 3) * g.OW + (e4 & 7) * 4);
+                    dv[4 * i + 0] = v.x; dv[4 * i + 1] = v.y; dv[4 * i + 2] = v.z; dv[4 * i + 3] = v.w;
+                }
+                const float* xbase = x + ((long)n * g.C + c_lo) * ihw + (long)iy0f * g.IW + (x0 - 4);
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (w_ck[i] >= 0 && (unsigned)(x0 - 4 + 4 * w_ck[i]) < (unsigned)g.IW) v = *reinterpret_cast<const float4*>(xbase + w_rel[i]);
+                    pv[4 * i + 0] = v.x; pv[4 * i + 1] = v.y; pv[4 * i + 2] = v.z; pv[4 * i + 3] = v.w;
+                }
+                return;
+            }
+            if (USE_PREL && interior) {
                 const long dshift = (long)y0 * g.OW + x0;
                 const long db = dy_bytes - dshift * 4;
                 const auto dsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dyp + dshift), 0, (int)(db < 0x7ffffff0L ? db : 0x7ffffff0L), 0x00020000);
@@ -145,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
                 const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + ((long)n * g.C + c_lo) * ihw + xshift), 0,
                                                                     (int)(xb < 0x7ffffff0L ? xb : 0x7ffffff0L), 0x00020000);
 #pragma unroll
-                for (int i = 0; i < WG_NPV; ++i) pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, prel[i], 0, 0));
+                for (int i = 0; i < WG_NPV; ++i) pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, prel[USE_PREL ? i : 0], 0, 0));
                 return;
             }
         }
@@ -179,6 +219,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     };
     auto store_tile = [&](int buf) {
         float* dd = D_lds + buf * WG_MT * WG_LDY;
+        if (loaded_wide) {
+#pragma unroll
+            for (int i = 0; i < NDY / 4; ++i) {
+                const int e4 = tid + NT * i;
+                // rows are 65 floats apart (conflict-free column reads), i.e. 4-byte aligned only: volatile keeps the four stores
+                // from being merged into one misaligned ds_write_b128
+                volatile float* row = dd + (e4 >> 4) * WG_LDY + ((e4 & 15) >> 3) * 32 + (e4 & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[j] = dv[4 * i + j];
+            }
+            float* pd = P_lds + buf * npatch;
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                if (w_ck[i] < 0) continue;
+                const int px0 = 4 * w_ck[i] - (4 - g.pad);               // patch column of the chunk's first float
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(px0 + j) < (unsigned)PW) pd[w_lds[i] + j] = pv[4 * i + j];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NDY; ++i) {
             const int e = tid + NT * i;
