@@ -16,6 +16,17 @@
 #include "common.h"
 #include "igemm_geom.h"
 
+#ifndef WG_TRACE
+#define WG_TRACE 0        // diagnostics (tools/variants.py + tools/wgrad_trace.py): block (0,0,0) stamps s_memtime of its tile phases into the head of dw
+#endif
+#if WG_TRACE
+#define WGT(k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && tile - tile0 >= 4 && tile - tile0 < 36) reinterpret_cast<unsigned*>(dw)[(tile - tile0 - 4) * 4 + (k)] = (v); } while (0)
+#define WGNOW() ((unsigned)__builtin_amdgcn_s_memtime())
+#else
+#define WGT(k, v) do { } while (0)
+#define WGNOW() 0u
+#endif
+
 namespace faoctasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -279,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     for (long tile = tile0; tile < tile1; ++tile) {
         const int cur = (int)(tile - tile0) & 1;
+        WGT(0, WGNOW());
         if (tile + 1 < tile1) load_tile(tile + 1);
+        WGT(1, WGNOW());
         // A fragment: D[m = l31 (+32)][pixel 2s + lh]; B fragment: P[bbase + pixel offset]
         // Addresses inside the tile are immediates of the LDS reads: pixel pair s of a row sits 8 S s bytes on, the second pixel
         // row S * PW floats further -- no address arithmetic between the MFMAs
@@ -335,8 +348,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WGT(2, WGNOW());
         if (tile + 1 < tile1) store_tile(cur ^ 1);
         __syncthreads();
+        WGT(3, WGNOW());
     }
 
     // epilogue: row m from the register index, column from the lane
@@ -351,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int m = m0 + (wm + mi) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                if (m < g.M) atomicAdd(dst + (long)m * g.wsm, acc[mi][ni][rr]);
+                if (m < g.M && !(WG_TRACE && m == 0)) atomicAdd(dst + (long)m * g.wsm, acc[mi][ni][rr]);
             }
     }
 }
