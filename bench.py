@@ -133,6 +133,22 @@ def hbm_kernels(device, images=512, H=256):
     return out
 
 
+def self_launch(n):
+    """Run this script as n ranks of one node under torch.distributed.run and return its exit code.  Nothing in this (parent)
+    process has initialised the GPU, it only waits; a failing rank makes torchrun -- and so the parent -- exit non-zero."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--force-launch"]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,19 +162,25 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
+    ap.add_argument("--force-launch", action="store_true", help="take the self-launch path (torch.distributed.run children) even for one GPU")
+    ap.add_argument("--ddp-graph", action="store_true", help="data-parallel runs: also measure the hipGraph-captured step (RCCL inside the capture)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_launch):
+        # plain `python bench.py --gpus N`: become a launcher BEFORE anything touches the GPU in this process -- the N ranks
+        # are children (one per GPU, torch.distributed.run), rank 0 prints the JSON line on the inherited stdout
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and world > 1:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("FAOCTASR_FORCE_DIST") == "1"     # the env var exercises the RCCL path at world 1
+    # under torch.distributed.run the RCCL path is taken at any world size (world 1 included: --force-launch rehearses it)
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("FAOCTASR_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.gpus > 1:
-        print("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
-        sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -168,10 +190,8 @@ def main():
     torch.manual_seed(0)
     import random
     random.seed(1234 + rank)
+    # distributed: TrainStep creates the RCCL communicator behind the C ABI and broadcasts rank 0's arenas / BN buffers
     ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision)
-    if distributed:                              # identical replicas: broadcast rank 0's arenas and buffers
-        for t in (ts.opt_G.flat, ts.opt_D.flat):
-            dist.broadcast(t, 0)
     B, H = args.batch, args.size
     real_A, real_B = make_batch(B, H, device, rank)
 
@@ -247,7 +267,8 @@ def main():
                                                   "wgrad and everything else f32",
                                          "parity": "step-0 losses within 1e-4, gradient norms within 2.3e-4 of the f32 path (tests/test_gpu_step.py)"}
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
-    if rank == 0 and not distributed and not args.no_graph:
+    # (data-parallel: every rank captures and replays in lockstep, RCCL's kernels are graph nodes -- opt-in with --ddp-graph)
+    if not args.no_graph and ((rank == 0 and not distributed) or (distributed and args.ddp_graph)):
         gs = faoctasr.GraphedTrainStep(ts, real_A, real_B)
         for _ in range(2):
             gs.step(real_A, real_B)
@@ -257,7 +278,7 @@ def main():
             gs.step(real_A, real_B)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        extra["hipgraph_step"] = {"value": round(B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
+        extra["hipgraph_step"] = {"value": round(world * B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
                                   "note": "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"}
         del gs
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -275,11 +296,13 @@ def main():
                 "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 split MFMA (fwd+dgrad), f32 wgrad", "data": "synthetic",
                 "config": {"workload": "%dx%dx1 OCTA pairs, batch %d per GPU, fp32, full G+D train step "
                                        "(4 frequency splits, 6 G fwd, 6 D fwd, 3 backward, 2 AdamW)" % (H, H, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss_G": round(loss_G, 5)},
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss_G": round(loss_G, 5),
+                           "rccl_ranks": ts.comm.ranks if ts.comm is not None else 0},
                 "roofline": roof, "cpu_baseline": cpu}
         line.update(extra)
         print(json.dumps(line), flush=True)
     if distributed:
+        ts.comm.close()
         dist.destroy_process_group()
 
 

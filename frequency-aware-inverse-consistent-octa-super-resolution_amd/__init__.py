@@ -9,7 +9,9 @@ from ._lib import KernelError
 from .model import (Discriminator, FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A, ResidualBlock, ResnetBlock,
                     ResnetGenerator, TVLoss, UnetGenerator, UnetSkipConnectionBlock, shallowNet)
 from .evaluate import evaluate_pairs, super_resolve
-from .ssim import SSIM, ssim
+from . import ssim                # stays the MODULE: the reference does `import ssim; ssim.SSIM()` (train.py:24,97)
+from .ssim import SSIM
+from .ssim import ssim as ssim_fn  # the function ssim.py:65-73; not exported under the submodule's name
 from .data import GpuTransformA, GpuTransformB, crop_resize_normalize, random_crop_offsets
 from .train import GraphedTrainStep, ParamArena, TrainStep, live_parameters
 from .utils import (DeviceReplayBuffer, LambdaLR, ReplayBuffer, frequency_split, high_pass, low_pass, psnr, set_requires_grad, weights_init_normal)

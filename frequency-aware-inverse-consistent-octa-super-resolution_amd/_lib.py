@@ -54,6 +54,13 @@ _SIG = {
     "adamw_step_dev": (_I, "pppp l p p"),
     "prep_crop_resize": (_I, "pppp iiiii ff p"),
     "fill": (_I, "p l f p"),
+    "circulant_lowpass": (_I, "p i f p"),
+    "comm_unique_id": (_I, "p"),
+    "comm_create": (_I, "p ii p"),
+    "comm_destroy": (_I, "p"),
+    "comm_size": (_I, "p"),
+    "grad_allreduce": (_I, "p l i p p"),
+    "param_broadcast": (_I, "p l i p p"),
 }
 _CODE = {"p": _P, "i": _I, "l": _L, "f": _F}
 

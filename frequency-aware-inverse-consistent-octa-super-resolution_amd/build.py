@@ -1,35 +1,75 @@
-"""Build libfaoctasr.so (hipcc, gfx950 only) in-tree, next to this file."""
+"""Build libfaoctasr.so (hipcc, gfx950 only) in-tree, next to this file.
+
+One object per source under ``build/obj`` (git-ignored), compiled in parallel and reused while its source and the shared
+headers are older than it; the link step runs whenever any object is newer than the library.  ``build()`` reports what it
+compiled, so a driver log shows whether the check really exercised the compiler (``force=True`` recompiles everything)."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "wgrad_patch.hip", "conv_m1.hip", "pointwise.hip", "sgemm.hip", "ssim.hip"]
+SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "wgrad_patch.hip", "conv_m1.hip", "pointwise.hip", "sgemm.hip",
+           "ssim.hip", "comm.hip"]
+HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(ROOT, "include", "faoctasr.h")]
 LIB = os.path.join(HERE, "libfaoctasr.so")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _flags():
+    extra = os.environ.get("FAOCTASR_HIPCC_FLAGS", "").split()
+    return ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"] + extra + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, "csrc", s) for s in SOURCES] + [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(ROOT, "include", "faoctasr.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def needs_build():
+    srcs = [os.path.join(HERE, "csrc", s) for s in SOURCES]
+    return _stale(LIB, srcs + HEADERS)
+
+
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [os.path.join(HERE, "csrc", s) for s in SOURCES if os.path.exists(os.path.join(HERE, "csrc", s))]
-    extra = os.environ.get("FAOCTASR_HIPCC_FLAGS", "").split()
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17"] + extra + ["-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(HERE, "csrc")] + srcs + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    tag = "_".join(os.environ.get("FAOCTASR_HIPCC_FLAGS", "").split()).replace("/", "_").replace("=", "-")
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(HERE, "csrc", s)
+        obj = os.path.join(OBJ_DIR, s + (("." + tag) if tag else "") + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append((s, [hipcc] + _flags() + ["-c", src, "-o", obj]))
+
+    def run(job):
+        name, cmd = job
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (name, " ".join(cmd), r.stdout))
+        return name
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            done = list(ex.map(run, jobs))
+        if verbose:
+            print("compiled for gfx950:", " ".join(done))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", LIB + ".tmp"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        os.replace(LIB + ".tmp", LIB)
+        if verbose:
+            print("linked", LIB)
+    elif verbose:
+        print("up to date:", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -10,6 +10,11 @@ namespace faoctasr {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute is issued once per (kernel, size step), not
+// per launch: the only process-wide state of the library is this grow-only record of attributes already set
+// (one process drives one GPU).
+void lds_optin(const void* kernel, size_t lds_bytes);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FAOCTASR_EHIP, "%s: %s", what, hipGetErrorString(e));

@@ -139,7 +139,7 @@ int launch_conv_m1_wgrad(const float* x, const float* dy, float* dw, int N, int 
     const int tpb = (int)((ntiles + gx - 1) / gx);
     gx = (ntiles + tpb - 1) / tpb;
     auto k = conv_m1_wgrad_kernel;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_optin((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)gx, gy), dim3(256), lds, st, x, dy, dw, N, C, H, W, KH, KW, pad, tpb, CCH);
     return check_launch("conv_m1_wgrad");
 }

@@ -494,16 +494,15 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     // persistent blocks: one block per CU walks tiles bx, bx + gridDim.x, ... (the pipeline continues across tile boundaries)
     long nbx = 256 / ((long)gy * g.nphase * ksplit);
     nbx = nbx < 1 ? 1 : nbx;
-    static const int persist = getenv("FAOCTASR_SPLIT_PERSIST") ? atoi(getenv("FAOCTASR_SPLIT_PERSIST")) : 1;
-    if (!persist || nbx > mx) nbx = mx;
+    if (nbx > mx) nbx = mx;
     dim3 grid((unsigned)nbx, gy, g.nphase * ksplit);
     if (g.SI == 1) {
         auto k = igemm_bf16x3_kernel<NI, 1>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_optin((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     } else {
         auto k = igemm_bf16x3_kernel<NI, 2>;
-        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_optin((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
     }
     return check_launch("igemm_bf16x3");

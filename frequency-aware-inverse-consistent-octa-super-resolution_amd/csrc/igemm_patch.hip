@@ -524,11 +524,8 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
         }
         if (ok && (asc || desc)) { dkw = kw; dord = asc ? 1 : -1; }
     }
-    if (getenv("FAOCTASR_DEBUG_DENSE"))
-        fprintf(stderr, "patch cfg <%d,%d,%d,%d> SI=%d nphase=%d T0=%d kc=%d span=(%d,%d) dense kw=%d ord=%d\n", WM, WN, MI, NI, g.SI, g.nphase,
-                g.t0[1] - g.t0[0], g.kc[0], g.span_y[0], g.span_x[0], dkw, dord);
     auto launch = [&](auto k) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_optin((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
     };
     bool done = false;
@@ -559,11 +556,11 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
     if (done) {
     } else if (g.SI == 1) {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 1>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_optin((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
     } else {
         auto k = igemm_patch_kernel<WM, WN, MI, NI, 2>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_optin((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, x, wp, bias, y, g, ksplit);
     }
     return check_launch("igemm_patch");
@@ -601,10 +598,7 @@ int launch_patch(const float* x, const float* wp, const float* bias, float* y, P
         if (g.gw[p] < 24 || g.t0[p + 1] - g.t0[p] == 0) return 0;       // narrow maps: the flat kernel wastes fewer lanes
     // config A: 128 x (4x32); B: 64 x (8x32); C: 64 x (4x32)
     int rc;
-    static const int force = getenv("FAOCTASR_PATCH_CFG") ? atoi(getenv("FAOCTASR_PATCH_CFG")) : 0;
-    if (force == 2 && patch_fits<1, 4, 2, 2>(g, g.SI)) {
-        rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);
-    } else if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
+    if (g.M > 64 && patch_fits<2, 2, 2, 2>(g, g.SI)) {
         rc = launch_cfg<2, 2, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<2, 2, 2, 2>(g), act), s);
     } else if (patch_fits<1, 4, 2, 2>(g, g.SI) && patch_blocks<1, 4, 2, 2>(g) >= 256) {
         rc = launch_cfg<1, 4, 2, 2>(x, wp, bias, y, g, pick_ksplit(g, patch_blocks<1, 4, 2, 2>(g), act), s);

@@ -28,10 +28,17 @@
 #include "igemm_geom.h"
 
 #ifndef WINO_TRACE
-#define WINO_TRACE 0       // diagnostics (tools/variants.py + tools/wino_trace.py): block 0 stamps s_memtime of its phases behind the bias vector
+#define WINO_TRACE 0       // diagnostics (tools/variants.py + tools/wino_trace.py): block 0 stamps s_memtime of its phases
 #endif
 #if WINO_TRACE
-#define WTRACE(cond, base, q, k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (cond) && (q) >= 16 && (q) < 48) reinterpret_cast<unsigned*>(const_cast<float*>(bias))[(base) + ((q) - 16) * 4 + (k)] = (v); } while (0)
+// The stamps go to a buffer of their own inside the code object (never through an operand pointer: round 1 wrote them behind
+// `bias`, which is NULL or M floats long in every model layer) and are read back with faoctasr_wino_trace_read.
+__device__ unsigned faoctasr_wino_trace_buf[4096];
+extern "C" int faoctasr_wino_trace_read(unsigned* host_out, int n) {
+    if (!host_out || n < 0 || n > 4096) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(faoctasr_wino_trace_buf), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#define WTRACE(cond, base, q, k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (cond) && (q) >= 16 && (q) < 48) faoctasr_wino_trace_buf[(base) + ((q) - 16) * 4 + (k)] = (v); } while (0)
 #define WNOW() ((unsigned)__builtin_amdgcn_s_memtime())
 #else
 #define WTRACE(cond, base, q, k, v) do { } while (0)
@@ -528,9 +535,8 @@ long wino_pack_floats_for(const IgemmGeom& f) {
 
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
              int wpack_state, hipStream_t s) {
-    static const int enabled = getenv("FAOCTASR_WINOGRAD") ? atoi(getenv("FAOCTASR_WINOGRAD")) : 1;
     WinoGeom g;
-    if (!enabled || !wino_geom_from(f, g) || !wino_worth(g)) return 0;
+    if (!wino_geom_from(f, g) || !wino_worth(g)) return 0;
     g.act = act; g.slope = slope;
     if (wpack_state == 1) {
         const long total = (long)g.mtiles * g.nchunks * WN_U_FLOATS;
@@ -546,7 +552,7 @@ int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bi
     nbx = nbx > tiles ? tiles : nbx;
     const size_t lds = (3 * (size_t)WN_U_FLOATS + 2 * (size_t)WN_V_FLOATS) * 4;
     auto k = igemm_wino_kernel;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_optin((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nbx, g.mtiles), dim3(512), lds, s, x, wpack, bias, y, g);
     const int rc = check_launch("igemm_wino");
     return rc == FAOCTASR_OK ? 1 : rc;

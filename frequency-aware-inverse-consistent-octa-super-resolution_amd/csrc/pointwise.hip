@@ -1,6 +1,8 @@
 // HBM-bound kernels of the train step: BatchNorm2d(train)/InstanceNorm2d with fused
 // activation + residual, activations, cat, Haar DWT/IDWT, frequency-split mixing, losses,
 // discriminator head, AdamW.  All fp32, NCHW, float4-vectorised where the shape allows.
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 
 namespace faoctasr {
@@ -13,6 +15,17 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+void lds_optin(const void* kernel, size_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[kernel];
+    if (have >= lds_bytes) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    have = lds_bytes;
 }
 
 static inline int grid_for(long n, int per_block, int cap = 4096) {

@@ -55,6 +55,28 @@ __global__ __launch_bounds__(256) void sgemm_batched_kernel(const float* __restr
     }
 }
 
+
+// The n x n circulant of the reference's Gaussian low-pass (utils.py:71-80 mask, 107-117 filter): the centred taps
+// g[k] = exp(-(k - int(n/2))^2 / (2 r^2)) meet spectrum bin k at g[(k + n/2) mod n] (fftshift, mask, ifftshift), so the
+// filter is multiplication by C[a][b] = c[(a - b) mod n], c = real(ifft(t)), t[k] = g[(k + n/2) mod n].  Built once per
+// (n, radius) in double precision on the device; the caller owns and caches the matrix (the ABI never allocates).
+__global__ __launch_bounds__(256) void circulant_lowpass_kernel(float* __restrict__ out, int n, double inv2r2) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * n) return;
+    const int a = (int)(e / n), b = (int)(e % n);
+    const int j = ((a - b) % n + n) % n;
+    const int c0 = n / 2;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const int kk = (k + c0) % n;
+        const double d = (double)(kk - c0);
+        const double t = exp(-d * d * inv2r2);
+        const long ph = ((long)k * j) % n;                    // exact phase reduction: cos(2 pi k j / n)
+        s += t * cospi(2.0 * (double)ph / (double)n);
+    }
+    out[e] = (float)(s / (double)n);
+}
+
 }  // namespace faoctasr
 
 using namespace faoctasr;
@@ -69,4 +91,13 @@ extern "C" int faoctasr_sgemm_batched(const float* A, const float* B, float* C, 
     hipLaunchKernelGGL(sgemm_batched_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, strideA, strideB,
                        strideC);
     return check_launch("sgemm_batched");
+}
+
+extern "C" int faoctasr_circulant_lowpass(float* out, int n, float radius, faoctasr_stream_t stream) {
+    if (!out) return fail(FAOCTASR_EINVAL, "circulant_lowpass: null pointer");
+    if (n < 1 || n > 8192 || !(radius > 0.f)) return fail(FAOCTASR_EINVAL, "circulant_lowpass: n %d, radius %g", n, (double)radius);
+    const long total = (long)n * n;
+    hipLaunchKernelGGL(circulant_lowpass_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       0.5 / ((double)radius * (double)radius));
+    return check_launch("circulant_lowpass");
 }

@@ -17,10 +17,16 @@
 #include "igemm_geom.h"
 
 #ifndef WG_TRACE
-#define WG_TRACE 0        // diagnostics (tools/variants.py + tools/wgrad_trace.py): block (0,0,0) stamps s_memtime of its tile phases into the head of dw
+#define WG_TRACE 0        // diagnostics (tools/variants.py + tools/wgrad_trace.py): block (0,0,0) stamps s_memtime of its tile phases
 #endif
 #if WG_TRACE
-#define WGT(k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && tile - tile0 >= 4 && tile - tile0 < 36) reinterpret_cast<unsigned*>(dw)[(tile - tile0 - 4) * 4 + (k)] = (v); } while (0)
+// stamps live in a buffer of their own (never in an operand: round 1 wrote them into the head of dw), read by faoctasr_wgrad_trace_read
+__device__ unsigned faoctasr_wgrad_trace_buf[128];
+extern "C" int faoctasr_wgrad_trace_read(unsigned* host_out, int n) {
+    if (!host_out || n < 0 || n > 128) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(faoctasr_wgrad_trace_buf), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#define WGT(k, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && tile - tile0 >= 4 && tile - tile0 < 36) faoctasr_wgrad_trace_buf[(tile - tile0 - 4) * 4 + (k)] = (v); } while (0)
 #define WGNOW() ((unsigned)__builtin_amdgcn_s_memtime())
 #else
 #define WGT(k, v) do { } while (0)
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(const float* __rest
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
                 const int m = m0 + (wm + mi) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                if (m < g.M && !(WG_TRACE && m == 0)) atomicAdd(dst + (long)m * g.wsm, acc[mi][ni][rr]);
+                if (m < g.M) atomicAdd(dst + (long)m * g.wsm, acc[mi][ni][rr]);
             }
     }
 }
@@ -391,7 +397,7 @@ static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hip
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     slices = (ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
     auto k = wgrad_patch_kernel<NI, S>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_optin((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3(gx, gy, (unsigned)slices), dim3(NT), lds, s, x, dy, dw, g);
     return true;
 }
@@ -400,9 +406,7 @@ static bool wg_try(const float* x, const float* dy, float* dw, WgradGeom& g, hip
 // the running gradient (accumulation is by atomics).
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
-    // stride-2 layers (large patches, small slabs) measured faster on the flat kernel
-    static const int s2 = getenv("FAOCTASR_WGRAD_S2") ? atoi(getenv("FAOCTASR_WGRAD_S2")) : 1;
-    if (OW < 24 || (stride != 1 && !(stride == 2 && s2)) || KH > 15 || KW > 15 || C * KH * KW < 64) return 0;
+    if (OW < 24 || (stride != 1 && stride != 2) || KH > 15 || KW > 15 || C * KH * KW < 64) return 0;
     WgradGeom g;
     g.N = N; g.C = C; g.IH = IH; g.IW = IW; g.M = M; g.OH = OH; g.OW = OW; g.S = stride; g.pad = pad; g.KH = KH; g.KW = KW;
     g.reflect = reflect; g.wsm = wsm; g.wsc = wsc; g.ncols = C * KH * KW;

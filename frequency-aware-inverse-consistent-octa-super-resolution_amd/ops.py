@@ -8,7 +8,6 @@ train.TrainStep), so no per-parameter add kernels run and the all-reduce sees on
 """
 import math
 
-import numpy as np
 import torch
 from torch.autograd import Function
 
@@ -506,15 +505,16 @@ _circ_cache = {}
 
 def circulant_lowpass(n, radius, device):
     """Real symmetric circulant C with C x == ifft(ifftshift(g) * fft(x)) for the centred Gaussian taps
-    g[k] = exp(-(k - int(n/2))^2 / (2 r^2)) of utils.py:71-80 (the 2-D mask is the outer product g g^T)."""
-    key = (n, float(radius), str(device))
+    g[k] = exp(-(k - int(n/2))^2 / (2 r^2)) of utils.py:71-80 (the 2-D mask is the outer product g g^T).  Built on the device
+    by ``faoctasr_circulant_lowpass`` once per (n, radius, device); this dict is the caller-owned filter cache of SURVEY 8b."""
+    device = torch.device(device)
+    key = (n, float(radius), device.type, device.index if device.index is not None else torch.cuda.current_device())
     c = _circ_cache.get(key)
     if c is None:
-        k = np.arange(n)
-        taps = np.exp(-0.5 * (k - int(n / 2)) ** 2 / float(radius) ** 2)
-        col = np.real(np.fft.ifft(np.fft.ifftshift(taps)))
-        mat = col[(k[:, None] - k[None, :]) % n]
-        c = torch.from_numpy(mat.astype(np.float32)).to(device).contiguous()
+        if device.type != "cuda":
+            raise _lib.KernelError("circulant_lowpass: the filter matrices are built by a HIP kernel; got device %s" % device)
+        c = torch.empty((n, n), dtype=torch.float32, device=device)
+        call("circulant_lowpass", ptr(c), n, float(radius), stream_ptr())
         _circ_cache[key] = c
     return c
 

@@ -7,6 +7,7 @@ data-parallel exchange is one all-reduce per phase), the targets and the replay 
 ``step(real_A, real_B)`` is one loop-body iteration.  The only semantic extension is the batched
 per-sample frequency split (the reference supports batch 1 only: SURVEY.md fact 3).
 """
+import ctypes
 import math
 import random
 import struct
@@ -15,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from ._lib import call, ptr, stream_ptr
+from ._lib import KernelError, call, ptr, stream_ptr
 from .model import FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A
 from .utils import DeviceReplayBuffer, ReplayBuffer, set_requires_grad, weights_init_normal
 from .wavelets import DWTForward
@@ -29,6 +30,49 @@ DEAD_PREFIXES = {"NetworkA2B": ("unet.", "unet_up."), "NetworkB2A": ("skip.",)}
 def live_parameters(net):
     dead = DEAD_PREFIXES.get(type(net).__name__, ())
     return [(n, p) for n, p in net.named_parameters() if not n.startswith(dead)]
+
+
+class GradComm:
+    """RCCL communicator behind the C ABI (``faoctasr_comm_*``, ``faoctasr_grad_allreduce``): one per process, bound to the
+    current device.  The 128-byte RCCL id travels from group rank 0 over the already-initialised ``torch.distributed`` group
+    (host channel only; the gradient bytes themselves never go through torch)."""
+
+    def __init__(self, group=None):
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            call("comm_unique_id", ident)
+        box = [bytes(ident.raw) if self.rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        handle = ctypes.c_void_p()
+        call("comm_create", ctypes.byref(handle), self.world, self.rank, box[0])
+        self.handle = handle
+        self.ranks = _lib_int("comm_size", handle)
+        if self.ranks != self.world:
+            raise KernelError("RCCL communicator spans %d ranks, the process group %d" % (self.ranks, self.world))
+
+    def all_reduce(self, t):
+        call("grad_allreduce", ptr(t), t.numel(), 0, self.handle, stream_ptr())
+
+    def broadcast(self, t, root=0):
+        call("param_broadcast", ptr(t), t.numel(), root, self.handle, stream_ptr())
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            call("comm_destroy", self.handle)
+            self.handle = None
+
+
+def _lib_int(name, *args):
+    """C-ABI queries that return a count (negative = error code)."""
+    from . import _lib
+    lib = _lib.load()
+    v = getattr(lib, "faoctasr_" + name)(*args)
+    if v < 0:
+        raise KernelError("faoctasr_%s failed (%d): %s" % (name, v, lib.faoctasr_last_error().decode()))
+    return v
 
 
 class ParamArena:
@@ -65,10 +109,14 @@ class ParamArena:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
-    def all_reduce(self, group=None):
-        """Sum gradients over ranks (RCCL when the tensors live on a GPU); the 1/world average is folded
-        into the AdamW kernel's grad_scale."""
-        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+    def all_reduce(self, group=None, comm=None):
+        """Sum gradients over ranks; the 1/world average is folded into the AdamW kernel's grad_scale.  With a ``GradComm``
+        this is ``faoctasr_grad_allreduce`` (RCCL over xGMI, enqueued on the current stream, capturable); host arenas (the
+        gloo CPU tests) go through ``torch.distributed``."""
+        if comm is not None:
+            comm.all_reduce(self.grad)
+        else:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
 
     def step(self, grad_scale=1.0, hyper=None):
         """``hyper``: device tensor of 8 floats (``hyper_values``) -- the captured-graph form, whose scalars are read on the device."""
@@ -119,6 +167,24 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self._targets = {}
         self.device = dev
+        self.comm = None
+        if self.distributed:
+            if dev.type != "cuda":
+                raise KernelError("TrainStep(distributed=True) needs a GPU: the exchange is RCCL behind the C ABI")
+            torch.cuda.set_device(dev)
+            self.comm = GradComm(process_group)
+            self.sync_replicas()
+
+    def sync_replicas(self, root=0):
+        """Replicas start identical (what DDP's constructor does): rank ``root``'s parameter arenas, AdamW moments and the float
+        buffers (BatchNorm running statistics) of the four networks go to every rank."""
+        for a in (self.opt_G, self.opt_D):
+            for t in (a.flat, a.exp_avg, a.exp_avg_sq):
+                self.comm.broadcast(t, root)
+        for net in (self.netG_A2B, self.netG_B2A, self.netD_A, self.netD_B):
+            for b in net.buffers():
+                if b.dtype == torch.float32 and b.numel():
+                    self.comm.broadcast(b, root)
 
     # -- pieces of the loop body ---------------------------------------------------------
     def targets(self, B):
@@ -186,7 +252,7 @@ class TrainStep:
         L = self.generator_loss(o, real_A, real_B)
         L["loss_G"].backward()
         if self.distributed:
-            self.opt_G.all_reduce(self.group)
+            self.opt_G.all_reduce(self.group, self.comm)
         self.opt_G.step(1.0 / self.world, None if _static is None else _static["hyper_G"])
         # (3) discriminators, train.py:242-269
         set_requires_grad([self.netD_A, self.netD_B], True)
@@ -198,7 +264,7 @@ class TrainStep:
         L["loss_D_B"] = ops.mse_loss(self.netD_B(real_B), ones, 0.5) + ops.mse_loss(self.netD_B(fake_B.detach()), zeros, 0.5)
         L["loss_D_B"].backward()
         if self.distributed:
-            self.opt_D.all_reduce(self.group)
+            self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
         ops.conv_precision = 0
         out = {k: v.detach() for k, v in L.items()}
@@ -238,12 +304,11 @@ class GraphedTrainStep:
     random decisions are still drawn on the host, in the reference's order, but reach the device as two small index tensors),
     and AdamW reads its learning rate and bias corrections from device memory (``faoctasr_adamw_step_dev``).  Capturing does not
     advance the training state: the warm-up steps that populate the allocator, the packed-weight buffers and the cached
-    circulants run on a snapshot that is restored before the capture.  Single process only (an RCCL exchange inside a capture
-    is not attempted)."""
+    circulants run on a snapshot that is restored before the capture.  A data-parallel step is captured the same way: the two
+    gradient all-reduces are ``faoctasr_grad_allreduce`` calls on the capturing stream, so RCCL's kernels become graph nodes
+    (BASELINE config 5); every rank must construct and replay its graph in lockstep, as with any collective."""
 
     def __init__(self, ts, real_A, real_B, warmup=2):
-        if ts.distributed:
-            raise RuntimeError("GraphedTrainStep: data-parallel steps are not captured; use TrainStep.step")
         self.ts = ts
         dev = ts.device
         B = real_A.shape[0]
@@ -312,7 +377,7 @@ class GraphedTrainStep:
             self._static[key][1].copy_(torch.tensor(dst, dtype=torch.long))
         for key, opt in (("hyper_G", ts.opt_G), ("hyper_D", ts.opt_D)):
             opt.step_count += 1
-            self._static[key].copy_(torch.tensor(opt.hyper_values(opt.step_count, 1.0), dtype=torch.float32))
+            self._static[key].copy_(torch.tensor(opt.hyper_values(opt.step_count, 1.0 / ts.world), dtype=torch.float32))
         self.graph.replay()
         for m, d in zip(self._bns, self._bn_delta):
             m._pending_batches += d

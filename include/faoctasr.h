@@ -139,11 +139,16 @@ int faoctasr_haar_dfront_bwd(const float* dy, float* dx, int N, int H, int W, in
 /* ---- FFT Gaussian frequency split as circulant GEMMs ---------------------------------------
  * utils.high_pass / utils.low_pass (utils.py:71-117) as called at train.py:173-175,189-191,
  * 197-199,211-213.  The shifted Gaussian mask is separable, so ifft2(mask*fft2(x)) = Ch x Cw^T
- * with real symmetric circulant matrices built once per (n, radius) by the host.
+ * with real symmetric circulant matrices built once per (n, radius) (faoctasr_circulant_lowpass).
  * Batched row-major SGEMM on f32 MFMA: for b in [0,batch): C_b = A_b(MxK) * B_b(KxN).         */
 int faoctasr_sgemm_batched(const float* A, const float* B, float* C, int M, int N, int K,
                            int lda, int ldb, int ldc, long strideA, long strideB, long strideC, int batch,
                            faoctasr_stream_t stream);
+/* The filter cache entry for one (n, radius): out[n*n] = the real symmetric circulant of the centred Gaussian mask of
+ * utils.py:71-80 (guais_low_pass; the high-pass mask is 1 - it), built in double precision on the device.  SURVEY 8b asks
+ * for an immutable (H,W,r)-keyed cache behind a create/destroy handle; because this ABI never allocates, the entry is a
+ * caller-owned buffer instead: build it once per (n, radius, device) with this call and keep it as long as needed.    */
+int faoctasr_circulant_lowpass(float* out, int n, float radius, faoctasr_stream_t stream);
 /* hf = (|x - low_hp| + x)/2, lf = -|low_lp|  (train.py:173-175) */
 int faoctasr_freq_mix_fwd(const float* x, const float* low_hp, const float* low_lp, float* hf, float* lf,
                           long n, faoctasr_stream_t stream);
@@ -189,6 +194,22 @@ int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n
  * transforms_A = crop 128 -> 256 bicubic; transforms_B = crop 256, no resize (the Normalize/RandomCrop order there commutes). */
 int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const int* lefts, float* out, int N, int H, int W,
                               int crop, int out_size, float mean, float std, faoctasr_stream_t stream);
+
+/* ---- data-parallel gradient exchange over RCCL ---------------------------------------------------------
+ * The reference has no distributed code; a DDP wrap of its loop would all-reduce after loss_G.backward() (train.py:238) and
+ * after the discriminator backwards (train.py:255,267).  Here that is ONE in-place SUM all-reduce per flat gradient arena,
+ * enqueued on the caller's stream (capturable in a hipGraph); the 1/world average is folded into adamw_step's grad_scale.
+ * librccl is bound at run time (dlopen; the copy already in the process when there is one) -- single-GPU hosts never load it.
+ * comm handles: rank 0 fills a 128-byte id (ncclUniqueId) and ships it to the other ranks by any host channel; every rank
+ * then calls comm_create with the device it will use current.  These three calls are the only ones that create state.  */
+int faoctasr_comm_unique_id(void* id128);
+int faoctasr_comm_create(void** comm, int nranks, int rank, const void* id128);
+int faoctasr_comm_destroy(void* comm);
+int faoctasr_comm_size(void* comm);                 /* number of ranks (> 0) or a negative error */
+/* dtype: 0 = fp32 (the only arena type) */
+int faoctasr_grad_allreduce(float* bucket, long count, int dtype, void* comm, faoctasr_stream_t stream);
+/* identical replicas at start: rank `root`'s parameter arena / BatchNorm buffers to everyone, in place */
+int faoctasr_param_broadcast(float* buf, long count, int root, void* comm, faoctasr_stream_t stream);
 
 /* ---- utility ---------------------------------------------------------------------------------- */
 int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream);

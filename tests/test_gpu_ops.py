@@ -352,10 +352,10 @@ def test_ssim_vs_golden_and_oracle(fa, O):
     assert float(v) == pytest.approx(float(ops_g["ssim32_mean"]), rel=1e-5)
     close(ad.grad, ops_g["ssim32_grad1"], rtol=1e-3, atol=1e-6)
     close(bd.grad, ops_g["ssim32_grad2"], rtol=1e-3, atol=1e-6)
-    close(fa.ssim(dev(a), dev(b), size_average=False), ops_g["ssim32_per_sample"], rtol=1e-5, atol=1e-6)
+    close(fa.ssim.ssim(dev(a), dev(b), size_average=False), ops_g["ssim32_per_sample"], rtol=1e-5, atol=1e-6)
     a3 = torch.rand(1, 3, 24, 40, generator=gen)
     b3 = torch.rand(1, 3, 24, 40, generator=gen)
-    assert float(fa.ssim(dev(a3), dev(b3))) == pytest.approx(float(ops_g["ssim_c3"]), rel=1e-5)
+    assert float(fa.ssim.ssim(dev(a3), dev(b3))) == pytest.approx(float(ops_g["ssim_c3"]), rel=1e-5)
     # benchmark-size check against the oracle, including the per-sample gradient path
     ab = torch.rand(4, 1, 256, 256) * 2 - 1
     bb = (ab + 0.2 * torch.randn_like(ab)).clamp(-1, 1)
@@ -364,11 +364,11 @@ def test_ssim_vs_golden_and_oracle(fa, O):
     wt = torch.tensor([1.0, -2.0, 0.5, 3.0])
     (vr * wt).sum().backward()
     ad = dev(ab).requires_grad_(True)
-    vd = fa.ssim(ad, dev(bb), size_average=False)
+    vd = fa.ssim.ssim(ad, dev(bb), size_average=False)
     close(vd, vr, rtol=1e-5, atol=1e-6)
     (vd * dev(wt)).sum().backward()
     assert rel_l2(ad.grad, ar.grad) < 1e-4
-    assert float(fa.ssim(dev(ab), dev(ab))) == pytest.approx(1.0, abs=1e-6)     # identity property
+    assert float(fa.ssim.ssim(dev(ab), dev(ab))) == pytest.approx(1.0, abs=1e-6)     # identity property
 
 
 def test_losses_head_adamw(fa, O):
@@ -387,13 +387,23 @@ def test_losses_head_adamw(fa, O):
         close(ad.grad, ar.grad, rtol=1e-4, atol=1e-7)
         close(bd.grad, br.grad, rtol=1e-4, atol=1e-7)
     # the reference's BCE target-gradient fixture (train.py:230-231)
+    # replay oracle/gen_golden.py's draw order on its generator (seed 11) up to the BCE operands, then compare VALUES
     gen = torch.Generator().manual_seed(11)
-    # (value and grad are regenerated from the oracle-side statement: grad wrt target = -x/N)
-    xi, tt = torch.randn(2, 4, 6, 6), torch.randn(2, 4, 6, 6)
+    torch.randn(2, 3, 16, 16, generator=gen)
+    for s in [(2, 3, 2, 2), (2, 3, 3, 8, 8), (2, 3, 3, 4, 4), (2, 3, 3, 2, 2), (2, 3, 16, 16)]:
+        torch.randn(s, generator=gen)
+    torch.rand(2, 1, 64, 64, generator=gen); torch.randn(64, 64, generator=gen)
+    torch.rand(1, 192, 192, generator=gen); torch.rand(1, 30, 34, generator=gen)
+    torch.rand(2, 1, 32, 32, generator=gen); torch.randn(2, 1, 32, 32, generator=gen)
+    torch.rand(1, 3, 24, 40, generator=gen); torch.rand(1, 3, 24, 40, generator=gen)
+    xi = torch.randn(2, 4, 6, 6, generator=gen)
+    tt = torch.randn(2, 4, 6, 6, generator=gen)
     td = dev(tt).requires_grad_(True)
-    fa.ops.bce_with_logits(dev(xi), td).backward()
-    close(td.grad, -xi / xi.numel(), rtol=1e-5, atol=1e-8)
-    assert ops_g["bce_tgrad"].shape == (2, 4, 6, 6)
+    val = fa.ops.bce_with_logits(dev(xi), td)
+    val.backward()
+    assert float(val) == pytest.approx(float(ops_g["bce_val"]), rel=1e-5)
+    close(td.grad, ops_g["bce_tgrad"], rtol=1e-5, atol=1e-8)          # the reference's own target gradient
+    close(td.grad, -xi / xi.numel(), rtol=1e-5, atol=1e-8)            # = -x/N in closed form
     # discriminator head
     p, q = torch.randn(3, 1, 6, 6, generator=g), torch.randn(3, 1, 2, 2, generator=g)
     pr, qr = p.clone().requires_grad_(True), q.clone().requires_grad_(True)

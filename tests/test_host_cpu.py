@@ -173,3 +173,21 @@ def test_adamw_hyper_values_match_scalar_rounding():
         assert h[5] == float(np.float32(lr / (1.0 - b1 ** step)))
         assert h[6] == float(np.float32(1.0 / np.sqrt(1.0 - b2 ** step)))
         assert h[7] == 0.125
+
+
+def test_integration_md_import_block_runs_verbatim():
+    """the import lines a maintainer pastes into train.py:24-31 must execute as written, and
+    `ssim` must be the MODULE (the reference calls `ssim.SSIM()`, train.py:97)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    assert "import faoctasr.ssim as ssim" in block
+    ns = {}
+    exec(block, ns)
+    import types
+    assert isinstance(ns["ssim"], types.ModuleType)
+    crit = ns["ssim"].SSIM()                              # train.py:97
+    assert crit.window_size == 11 and callable(ns["ssim"].ssim)
+    for name in ("set_requires_grad", "weights_init_normal", "ReplayBuffer", "LambdaLR", "UnetGenerator", "FS_DiscriminatorA",
+                 "FS_DiscriminatorB", "NetworkA2B", "NetworkB2A", "TVLoss"):
+        assert name in ns
+    assert all(hasattr(ns["utils"], n) for n in ("high_pass", "low_pass", "ReplayBuffer", "LambdaLR"))

@@ -14,7 +14,10 @@ for _ in range(2):
     dw.zero_()
     call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, 3, 3, 1, 1, 0, 1, stream_ptr())
 torch.cuda.synchronize()
-t = dw.view(-1)[:128].view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff
+import ctypes, numpy as np
+raw = (ctypes.c_uint * 128)()
+assert _lib.load().faoctasr_wgrad_trace_read(raw, 128) == 0, "not a WG_TRACE=1 build (tools/variants.py)"
+t = np.frombuffer(raw, dtype=np.uint32).astype("int64")
 t = t.reshape(32, 4)
 d = lambda a, b: int((a - b) & 0xffffffff)
 print("tile | load-issue  mfma-loop  store+sync | total")

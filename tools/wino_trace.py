@@ -4,12 +4,15 @@ import faoctasr
 from faoctasr import ops
 faoctasr._lib.load()
 x = torch.randn(8, 64, 256, 256, device="cuda"); w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
-bias = torch.zeros(4096, device="cuda")          # rows 0..63 = the (zero) bias; the WINO_TRACE build stamps s_memtime behind it
+bias = None                                      # the WINO_TRACE build stamps s_memtime into its own device buffer
 with torch.no_grad():
     for _ in range(2):
         y = ops.conv2d(x, w, bias, 1, 1, False, None, 0.2)
 torch.cuda.synchronize()
-t = bias.view(torch.int32).cpu().numpy().astype("int64") & 0xffffffff
+import ctypes, numpy as np
+raw = (ctypes.c_uint * 4096)()
+assert faoctasr._lib.load().faoctasr_wino_trace_read(raw, 4096) == 0, "not a WINO_TRACE=1 build (tools/variants.py)"
+t = np.frombuffer(raw, dtype=np.uint32).astype("int64")
 p = t[1024:1152].reshape(32, 4); c = t[2048:2176].reshape(32, 4); u = t[3072:3200].reshape(32, 4)
 d = lambda a, b: int((a - b) & 0xffffffff)
 print("slab | transform wave: store_v  loads  barrier | weights wave: store  loads  barrier | consumer: mfma-loop  barrier  (to next slab start)")
