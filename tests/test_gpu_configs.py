@@ -80,11 +80,13 @@ def test_config3_b64_bf16x3_dwt3_vs_oracle(fa, O):
     a, b = O.synthetic_batch(B, H, seed=777)
     torch.set_num_threads(host_threads())
     S = O.StepOracle(seed=0, whf_weight=0.5, dwt_levels=3)
+    random.seed(4242)          # batch 64 overflows the 50-image replay buffer: the last 14 images draw from `random` (utils.py:41-50)
     Lo = S.train_step(a, b)
     go = S.grad_norms()
     del S
     gc.collect()
     ts = fresh_step(fa, O, precision="bf16x3", whf_weight=0.5, dwt_levels=3, distributed=False)
+    random.seed(4242)          # ... so both sides start the step from the same generator state
     L = ts.step(a.cuda(), b.cuda(), sync=True)
     for k in Lo:
         assert L[k] == pytest.approx(Lo[k], rel=1e-3, abs=2e-5), (k, L[k], Lo[k])
