@@ -171,7 +171,8 @@ class TrainStep:
         if self.distributed:
             if dev.type != "cuda":
                 raise KernelError("TrainStep(distributed=True) needs a GPU: the exchange is RCCL behind the C ABI")
-            torch.cuda.set_device(dev)
+            if dev.index is not None:
+                torch.cuda.set_device(dev)             # the communicator binds the calling thread's current device
             self.comm = GradComm(process_group)
             self.sync_replicas()
 
