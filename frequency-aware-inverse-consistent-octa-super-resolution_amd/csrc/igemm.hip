@@ -552,6 +552,9 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     if (OW >= 24) {      // wide maps: LDS-patch weight gradient (atomics into dw, zeroed here unless accumulating)
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
+        rc = launch_wgrad_s1(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
+                             (hipStream_t)stream);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
         rc = launch_wgrad_patch(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
                                 (hipStream_t)stream);
         if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;

@@ -71,6 +71,12 @@ CONV_CASES = [
     (4, 20, 33, 47, 70, 3, 1, 1, False, True, "lrelu"),       # odd height and width, channel and M tails, bias + activation
     (4, 64, 64, 64, 64, 3, 1, 1, False, False, None),         # c8-like
     (8, 256, 32, 32, 256, 3, 1, 1, False, False, None),       # c5 at the benchmark size: 256 blocks, 32 chunks
+    # weight gradient through wgrad_s1.hip (stride-1 "same" conv, M % 64 == 0, W % 32 == 0, even H, C*k*k >= 192)
+    (2, 64, 64, 64, 64, 7, 1, 3, True, True, None),           # reflect 7x7: mirrored rows, mirrored left / right border chunks
+    (1, 128, 32, 96, 64, 7, 1, 3, True, False, None),         # reflect, 3 tile columns: left border, interior, right border tiles
+    (3, 64, 6, 32, 64, 3, 1, 1, False, False, None),          # one tile column (left AND right border in one tile), 3 tile rows
+    (2, 16, 32, 64, 128, 5, 1, 2, False, True, None),         # 5x5 pad 2, two row blocks
+    (5, 24, 8, 64, 64, 3, 1, 1, False, False, None),          # 216 columns: a second, mostly empty slab; odd batch
 ]
 
 

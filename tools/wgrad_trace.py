@@ -7,7 +7,7 @@ import faoctasr
 from faoctasr import _lib
 from faoctasr._lib import call, ptr, stream_ptr
 _lib.load()
-N, C, H, W, M = 8, 64, 256, 256, 64
+N, C, H, W, M = [int(v) for v in sys.argv[1:6]] if len(sys.argv) > 5 else (8, 64, 256, 256, 64)
 x = torch.randn(N, C, H, W, device="cuda"); dy = torch.randn(N, M, H, W, device="cuda")
 dw = torch.zeros(M, C, 3, 3, device="cuda")
 for _ in range(2):
