@@ -26,11 +26,11 @@ _SIG = {
     "channel_sum": (_I, "pp iii i p"),
     "bn_workspace_floats": (_L, "i"),
     "batchnorm_train_fwd": (_I, "ppppppppp iii ff i f p p"),
-    "batchnorm_train_bwd": (_I, "pppppppppp iii i f i p p"),
+    "batchnorm_train_bwd": (_I, "ppppppppppp iii i f i p p"),
     "batchnorm_eval_fwd": (_I, "pppppp iii f i f p"),
     "batchnorm_eval_bwd": (_I, "ppppp iii f i f p"),
     "instancenorm_fwd": (_I, "pppppp iii f i f p p"),
-    "instancenorm_bwd": (_I, "ppppppppp iii i f p p"),
+    "instancenorm_bwd": (_I, "pppppppppp iii i f p p"),
     "act_fwd": (_I, "pp l i f p"),
     "act_bwd": (_I, "ppp l i f p"),
     "cat2_act_fwd": (_I, "ppp iiii i f p"),

@@ -35,214 +35,6 @@ static inline int grid_for(long n, int per_block, int cap = 4096) {
     return (int)b;
 }
 
-// ------------------------------------------------------------------------------------------
-// normalisation.  Rows r in [0,R): BatchNorm R = C (each row gathers N images x HW);
-// InstanceNorm R = N*C with N_img = 1.  Element e of row r lives at ((e/HW)*R + r)*HW + e%HW.
-// Statistics are accumulated around a per-row shift (the row's first element) to avoid the
-// E[x^2]-E[x]^2 cancellation.  Partials: ws[(r*S + s)*2 + {0,1}].
-// ------------------------------------------------------------------------------------------
-constexpr int BN_MAX_SPLIT = 64;
-
-__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int NI, int R,
-                                                         int HW, int S, long per) {
-    __shared__ float red[4];
-    const int r = blockIdx.y, s = blockIdx.x;
-    const long L = (long)NI * HW;
-    long e0 = (long)s * per, e1 = e0 + per;
-    if (e1 > L) e1 = L;
-    const float shift = x[(long)r * HW];
-    float a = 0.f, q = 0.f;
-    if ((HW & 3) == 0) {
-        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
-            const long n = e / HW;
-            const long i = e - n * HW;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((long)n * R + r) * HW + i);
-            float d;
-            d = v.x - shift; a += d; q += d * d;
-            d = v.y - shift; a += d; q += d * d;
-            d = v.z - shift; a += d; q += d * d;
-            d = v.w - shift; a += d; q += d * d;
-        }
-    } else {
-        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-            const long n = e / HW;
-            const long i = e - n * HW;
-            const float d = x[((long)n * R + r) * HW + i] - shift;
-            a += d; q += d * d;
-        }
-    }
-    a = block_sum_256(a, red);
-    q = block_sum_256(q, red);
-    if (threadIdx.x == 0) {
-        ws[((long)r * S + s) * 2 + 0] = a;
-        ws[((long)r * S + s) * 2 + 1] = q;
-    }
-}
-
-__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ res,
-                                                         float* __restrict__ y, float* __restrict__ save_mean,
-                                                         float* __restrict__ save_invstd, float* __restrict__ rmean,
-                                                         float* __restrict__ rvar, const float* __restrict__ ws, int NI, int R,
-                                                         int Cg, int HW, int S, float eps, float momentum, int act, float slope,
-                                                         long per) {
-    const int r = blockIdx.y;
-    const long L = (long)NI * HW;
-    float a = 0.f, q = 0.f;
-    for (int s = 0; s < S; ++s) {   // fixed order: deterministic
-        a += ws[((long)r * S + s) * 2 + 0];
-        q += ws[((long)r * S + s) * 2 + 1];
-    }
-    const float shift = x[(long)r * HW];
-    const float invL = 1.0f / (float)L;
-    const float dm = a * invL;
-    const float mean = shift + dm;
-    float var = q * invL - dm * dm;
-    var = var > 0.f ? var : 0.f;
-    const float invstd = 1.0f / sqrtf(var + eps);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        save_mean[r] = mean;
-        save_invstd[r] = invstd;
-        if (rmean) {
-            const float unb = L > 1 ? var * ((float)L / (float)(L - 1)) : var;
-            rmean[r] = (1.f - momentum) * rmean[r] + momentum * mean;
-            rvar[r] = (1.f - momentum) * rvar[r] + momentum * unb;
-        }
-    }
-    const int cg = r % Cg;
-    const float gsc = (gamma ? gamma[cg] : 1.f) * invstd;
-    const float bsh = (beta ? beta[cg] : 0.f) - mean * gsc;
-    long e0 = (long)blockIdx.x * per, e1 = e0 + per;
-    if (e1 > L) e1 = L;
-    if ((HW & 3) == 0) {
-        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            float4 v = *reinterpret_cast<const float4*>(x + off);
-            v.x = v.x * gsc + bsh; v.y = v.y * gsc + bsh; v.z = v.z * gsc + bsh; v.w = v.w * gsc + bsh;
-            if (res) {
-                const float4 rr = *reinterpret_cast<const float4*>(res + off);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
-            v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
-            *reinterpret_cast<float4*>(y + off) = v;
-        }
-    } else {
-        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            float v = x[off] * gsc + bsh;
-            if (res) v += res[off];
-            y[off] = act_apply(v, act, slope);
-        }
-    }
-}
-
-// backward reduce: s1 = sum dy', s2 = sum dy' * xhat, dy' = dy * act'(y)
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              const float* __restrict__ y, const float* __restrict__ save_mean,
-                                                              const float* __restrict__ save_invstd, float* __restrict__ ws,
-                                                              int NI, int R, int HW, int S, int act, float slope, long per) {
-    __shared__ float red[4];
-    const int r = blockIdx.y, s = blockIdx.x;
-    const long L = (long)NI * HW;
-    long e0 = (long)s * per, e1 = e0 + per;
-    if (e1 > L) e1 = L;
-    const float mean = save_mean[r], invstd = save_invstd[r];
-    float s1 = 0.f, s2 = 0.f;
-    if ((HW & 3) == 0) {
-        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            const float4 xv = *reinterpret_cast<const float4*>(x + off);
-            float4 g = *reinterpret_cast<const float4*>(dy + off);
-            if (act != FAOCTASR_ACT_NONE) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + off);
-                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
-                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
-            }
-            s1 += g.x + g.y + g.z + g.w;
-            s2 += g.x * ((xv.x - mean) * invstd) + g.y * ((xv.y - mean) * invstd) + g.z * ((xv.z - mean) * invstd) +
-                  g.w * ((xv.w - mean) * invstd);
-        }
-    } else {
-        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            float g = dy[off];
-            if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[off], act, slope);
-            s1 += g;
-            s2 += g * ((x[off] - mean) * invstd);
-        }
-    }
-    s1 = block_sum_256(s1, red);
-    s2 = block_sum_256(s2, red);
-    if (threadIdx.x == 0) {
-        ws[((long)r * S + s) * 2 + 0] = s1;
-        ws[((long)r * S + s) * 2 + 1] = s2;
-    }
-}
-
-__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ y, const float* __restrict__ gamma,
-                                                          const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
-                                                          float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          float* __restrict__ dres, const float* __restrict__ ws, int NI, int R, int Cg,
-                                                          int HW, int S, int act, float slope, long per, int accumulate_affine) {
-    const int r = blockIdx.y;
-    const long L = (long)NI * HW;
-    float s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < S; ++s) {
-        s1 += ws[((long)r * S + s) * 2 + 0];
-        s2 += ws[((long)r * S + s) * 2 + 1];
-    }
-    const int cg = r % Cg;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (accumulate_affine) {
-            if (dgamma) atomicAdd(dgamma + cg, s2);
-            if (dbeta) atomicAdd(dbeta + cg, s1);
-        } else {
-            if (dgamma) dgamma[cg] = s2;
-            if (dbeta) dbeta[cg] = s1;
-        }
-    }
-    const float mean = save_mean[r], invstd = save_invstd[r];
-    const float gi = (gamma ? gamma[cg] : 1.f) * invstd;
-    const float m1 = s1 / (float)L, m2 = s2 / (float)L;
-    long e0 = (long)blockIdx.x * per, e1 = e0 + per;
-    if (e1 > L) e1 = L;
-    if ((HW & 3) == 0) {
-        for (long e = e0 + 4L * threadIdx.x; e < e1; e += 1024) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            const float4 xv = *reinterpret_cast<const float4*>(x + off);
-            float4 g = *reinterpret_cast<const float4*>(dy + off);
-            if (act != FAOCTASR_ACT_NONE) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + off);
-                g.x *= act_grad_from_out(yv.x, act, slope); g.y *= act_grad_from_out(yv.y, act, slope);
-                g.z *= act_grad_from_out(yv.z, act, slope); g.w *= act_grad_from_out(yv.w, act, slope);
-            }
-            if (dres) *reinterpret_cast<float4*>(dres + off) = g;
-            float4 o;
-            o.x = gi * (g.x - m1 - (xv.x - mean) * invstd * m2);
-            o.y = gi * (g.y - m1 - (xv.y - mean) * invstd * m2);
-            o.z = gi * (g.z - m1 - (xv.z - mean) * invstd * m2);
-            o.w = gi * (g.w - m1 - (xv.w - mean) * invstd * m2);
-            *reinterpret_cast<float4*>(dx + off) = o;
-        }
-    } else {
-        for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-            const long n = e / HW;
-            const long off = ((long)n * R + r) * HW + (e - n * HW);
-            float g = dy[off];
-            if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[off], act, slope);
-            if (dres) dres[off] = g;
-            dx[off] = gi * (g - m1 - (x[off] - mean) * invstd * m2);
-        }
-    }
-}
-
 // inference-mode BatchNorm: per-channel affine from the running statistics
 __global__ void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ rmean, const float* __restrict__ rvar, float* __restrict__ y, int C, int HW,
@@ -265,52 +57,6 @@ __global__ void bn_eval_bwd_kernel(const float* __restrict__ dy, const float* __
         if (act != FAOCTASR_ACT_NONE) g *= act_grad_from_out(y[i], act, slope);
         dx[i] = g * (gamma ? gamma[c] : 1.f) / sqrtf(rvar[c] + eps);
     }
-}
-
-static void norm_split(long L, int R, int& S, long& per) {
-    // enough blocks to fill 256 CUs a few times over, each block >= 4096 elements
-    long want = (1024 + R - 1) / R;
-    long maxs = (L + 4095) / 4096;
-    long s = want < maxs ? want : maxs;
-    if (s < 1) s = 1;
-    if (s > BN_MAX_SPLIT) s = BN_MAX_SPLIT;
-    per = (L + s - 1) / s;
-    per = (per + 3) & ~3L;
-    S = (int)((L + per - 1) / per);
-}
-
-static int norm_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, float* save_mean,
-                    float* save_invstd, float* rmean, float* rvar, int NI, int R, int Cg, int HW, float eps, float momentum,
-                    int act, float slope, float* ws, hipStream_t st) {
-    if (!x || !y || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_fwd: null pointer");
-    if (NI <= 0 || R <= 0 || HW <= 0) return fail(FAOCTASR_EINVAL, "norm_fwd: bad shape");
-    const long L = (long)NI * HW;
-    int S; long per;
-    norm_split(L, R, S, per);
-    hipLaunchKernelGGL(norm_stats_kernel, dim3(S, R), dim3(256), 0, st, x, ws, NI, R, HW, S, per);
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(S, R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar,
-                       ws, NI, R, Cg, HW, S, eps, momentum, act, slope, per);
-    return check_launch("norm_fwd");
-}
-
-static int norm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
-                    const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dres, int NI, int R, int Cg, int HW,
-                    int act, float slope, int accumulate_affine, float* ws, hipStream_t st) {
-    if (!x || !dy || !dx || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_bwd: null pointer");
-    if (act != FAOCTASR_ACT_NONE && !y) return fail(FAOCTASR_EINVAL, "norm_bwd: activation mask needs the forward output");
-    const long L = (long)NI * HW;
-    int S; long per;
-    norm_split(L, R, S, per);
-    const int accumulate = (Cg != R) || accumulate_affine;
-    if (accumulate && !accumulate_affine) {
-        if (dgamma) (void)hipMemsetAsync(dgamma, 0, sizeof(float) * Cg, st);
-        if (dbeta) (void)hipMemsetAsync(dbeta, 0, sizeof(float) * Cg, st);
-    }
-    hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, ws, NI, R, HW, S, act,
-                       slope, per);
-    hipLaunchKernelGGL(norm_bwd_dx_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta,
-                       dres, ws, NI, R, Cg, HW, S, act, slope, per, accumulate);
-    return check_launch("norm_bwd");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -714,24 +460,8 @@ using namespace faoctasr;
 
 extern "C" {
 
-int faoctasr_version(void) { return 100; }
+int faoctasr_version(void) { return 200; }
 const char* faoctasr_last_error(void) { return err_buf(); }
-
-long faoctasr_bn_workspace_floats(int C) { return (long)C * BN_MAX_SPLIT * 2; }
-
-int faoctasr_batchnorm_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
-                                 float* save_mean, float* save_invstd, float* running_mean, float* running_var, int N, int C,
-                                 int HW, float eps, float momentum, int act, float slope, float* workspace, faoctasr_stream_t stream) {
-    return norm_fwd(x, gamma, beta, residual, y, save_mean, save_invstd, running_mean, running_var, N, C, C, HW, eps, momentum, act,
-                    slope, workspace, (hipStream_t)stream);
-}
-
-int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dres, int N, int C, int HW,
-                                 int act, float slope, int accumulate_affine, float* workspace, faoctasr_stream_t stream) {
-    return norm_bwd(x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, dres, N, C, C, HW, act, slope, accumulate_affine,
-                    workspace, (hipStream_t)stream);
-}
 
 int faoctasr_batchnorm_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                 float* y, int N, int C, int HW, float eps, int act, float slope, faoctasr_stream_t stream) {
@@ -752,20 +482,6 @@ int faoctasr_batchnorm_eval_bwd(const float* dy, const float* y, const float* ga
     hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, dy, y, gamma, running_var, dx, C,
                        HW, total, eps, act, slope);
     return check_launch("bn_eval_bwd");
-}
-
-// InstanceNorm2d = the same kernels over R = N*C rows of one image each (workspace: faoctasr_bn_workspace_floats(N*C))
-int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-                              int N, int C, int HW, float eps, int act, float slope, float* workspace, faoctasr_stream_t stream) {
-    return norm_fwd(x, gamma, beta, nullptr, y, save_mean, save_invstd, nullptr, nullptr, 1, N * C, C, HW, eps, 0.f, act, slope,
-                    workspace, (hipStream_t)stream);
-}
-
-int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
-                              const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, int HW, int act,
-                              float slope, float* workspace, faoctasr_stream_t stream) {
-    return norm_bwd(x, dy, y, gamma, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, 1, N * C, C, HW, act, slope, 0, workspace,
-                    (hipStream_t)stream);
 }
 
 int faoctasr_act_fwd(const float* x, float* y, long n, int act, float slope, faoctasr_stream_t stream) {

@@ -14,7 +14,8 @@
 //     OW % 32 == 0, OH even are required), a patch row is ten aligned 4-float chunks [x0-4+4k, +4) kept in LDS as loaded,
 //     zero padding = a chunk or a row that is not loaded, reflection = a redirected row / a mirrored chunk;
 //   * a wave owns all 64 rows of the block (MI = 2): the dY fragment is one ds_read_b128 per four k-steps and row block, so
-//     the loop issues (2 + 4 NI) LDS reads per 8 NI MFMAs (0.58 per MFMA at NI = 3; wgrad_patch.hip: 1.33);
+//     the column fragments come two k-steps at a time (ds_read2_b32): 2 + 2 NI LDS reads per 8 NI MFMAs (0.33 per MFMA at
+//     NI = 3; wgrad_patch.hip: 1.33);
 //   * WK = 2: the block's four waves are 2 (pixel rows of the tile) x 2 (column halves) for filters whose column count is a
 //     multiple of 192 (64x64x3x3: 576); the two pixel-row partials meet in LDS before the atomics.  WK = 1: 1 x 4 waves.
 // Partial sums over pixel ranges go to the gradient arena with fp32 atomics (dw is zeroed / accumulating, as before).
@@ -26,6 +27,7 @@ namespace faoctasr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WgS1Geom {
     int N, C, H, W;          // X and dY maps have the same extent (stride 1, pad = (K-1)/2)
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
                                                           const WgS1Geom g) {
     constexpr int WN = 4 / WK, CT = WN * NI * 32, KS = 32 / WK;          // k-steps (pixel pairs) per tile and wave
     constexpr int NQ = KS / 4;                                           // quads of k-steps = dY fragment reads
-    constexpr int NRD = 2 + 4 * NI;                                      // LDS reads per quad
+    constexpr int NRD = 2 + 2 * NI;                                      // LDS read instructions per quad
     static_assert(NRD <= 15, "counted lgkmcnt wait");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -248,43 +250,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
         for (int ni = 0; ni < NI; ++ni) ba[ni] = b_addr[ni] + cur * pbuf;
 
         f32x4 A0[2], A1[2];                                              // two named fragment sets (static indexing)
-        float B0[4][NI], B1[4][NI];
-        auto rd = [&](auto qc, f32x4 (&A)[2], float (&B)[4][NI]) {
+        f32x2 B0[2][NI], B1[2][NI];                                     // [k-step pair][column tile]
+        auto rd = [&](auto qc, f32x4 (&A)[2], f32x2 (&B)[2][NI]) {
             constexpr int q = decltype(qc)::value;
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[0]) : "v"(aa), "n"(16 * q));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[1]) : "v"(aa), "n"(16 * q + 32 * S1_LD * 4));
+            // two k-steps of a column per instruction (ds_read2_b32: same LDS cycles as two reads, one issue slot)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const unsigned b_ = ba[ni];                          // (asm operands cannot name a captured array element)
-                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(B[ks][ni]) : "v"(b_), "n"(4 * (4 * q + ks)));
+                    f32x2 v;
+                    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(b_), "n"(4 * q + 2 * kp), "n"(4 * q + 2 * kp + 1));
+                    B[kp][ni] = v;
                 }
         };
         // wait until at most `younger` LDS operations are outstanding; names the set so that its MFMAs stay behind the wait
-        auto wait_set = [&](f32x4 (&A)[2], float (&B)[4][NI], auto yc) {
+        auto wait_set = [&](f32x4 (&A)[2], f32x2 (&B)[2][NI], auto yc) {
             constexpr int younger = decltype(yc)::value;
             if constexpr (NI == 3)
-                asm volatile("s_waitcnt lgkmcnt(%14)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]),
-                             "+v"(B[1][2]), "+v"(B[2][0]), "+v"(B[2][1]), "+v"(B[2][2]), "+v"(B[3][0]), "+v"(B[3][1]), "+v"(B[3][2]) : "n"(younger));
+                asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[0][2]), "+v"(B[1][0]), "+v"(B[1][1]),
+                             "+v"(B[1][2]) : "n"(younger));
             else if constexpr (NI == 2)
-                asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[1][0]), "+v"(B[1][1]), "+v"(B[2][0]),
-                             "+v"(B[2][1]), "+v"(B[3][0]), "+v"(B[3][1]) : "n"(younger));
+                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[0][1]), "+v"(B[1][0]), "+v"(B[1][1]) : "n"(younger));
             else
-                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[1][0]), "+v"(B[2][0]), "+v"(B[3][0]) : "n"(younger));
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0][0]), "+v"(B[1][0]) : "n"(younger));
             __builtin_amdgcn_sched_barrier(0);
         };
         // staging slot of k-step s: stores of tile+1 in steps 0..NPIECE-1, loads of tile+2 in the last NPIECE steps
-        auto slot = [&](auto sc) {
+        // (STEADY: both hold -- no branches between the MFMAs of all but a block's last two tiles)
+        auto slot = [&](auto sc, auto steadyc) {
             constexpr int s = decltype(sc)::value;
+            constexpr bool STEADY = decltype(steadyc)::value;
             if constexpr (s < NPIECE) {
-                if (have_next) store_piece(cur ^ 1, sc);
+                if (STEADY || have_next) store_piece(cur ^ 1, sc);
             }
             if constexpr (s >= KS - NPIECE) {
-                if (have_nn) load_piece(nn, std::integral_constant<int, s - (KS - NPIECE)>{});
+                if (STEADY || have_nn) load_piece(nn, std::integral_constant<int, s - (KS - NPIECE)>{});
             }
         };
-        auto quad = [&](auto qc, f32x4 (&A)[2], float (&B)[4][NI], f32x4 (&An)[2], float (&Bn)[4][NI]) {
+        auto quad = [&](auto qc, auto steadyc, f32x4 (&A)[2], f32x2 (&B)[2][NI], f32x4 (&An)[2], f32x2 (&Bn)[2][NI]) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q + 1 < NQ) {
                 rd(std::integral_constant<int, q + 1>{}, An, Bn);
@@ -294,22 +300,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
             }
             s1_static_for<0, 4>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
-                slot(std::integral_constant<int, 4 * q + ks>{});
+                slot(std::integral_constant<int, 4 * q + ks>{}, steadyc);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mi][ks], B[ks][ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mi][ks], B[ks >> 1][ni][ks & 1], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
         rd(std::integral_constant<int, 0>{}, A0, B0);
-        s1_static_for<0, NQ / 2>([&](auto hc) {
-            constexpr int h = decltype(hc)::value;
-            quad(std::integral_constant<int, 2 * h>{}, A0, B0, A1, B1);
-            quad(std::integral_constant<int, 2 * h + 1>{}, A1, B1, A0, B0);
-        });
+        auto body = [&](auto steadyc) {
+            s1_static_for<0, NQ / 2>([&](auto hc) {
+                constexpr int h = decltype(hc)::value;
+                quad(std::integral_constant<int, 2 * h>{}, steadyc, A0, B0, A1, B1);
+                quad(std::integral_constant<int, 2 * h + 1>{}, steadyc, A1, B1, A0, B0);
+            });
+        };
+        body(std::false_type{});      // (a second, branch-free copy of the loop for the steady state was tried: the two copies spill 440 B/lane)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }

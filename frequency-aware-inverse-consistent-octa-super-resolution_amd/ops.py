@@ -219,7 +219,9 @@ class _BatchNormTrain(Function):
         ws = _lib.workspace(x.device, C * 128)
         call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(stats[0]), ptr(stats[1]),
              ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr())
-        ctx.save_for_backward(x, gamma, stats, y if act else None)
+        # the backward takes the ReLU / LeakyReLU mask from x when there was no residual (faoctasr.h): y is then not kept by this node
+        need_y = act == ACT_TANH or (act and residual is not None)
+        ctx.save_for_backward(x, gamma, stats, y if need_y else None, beta if (act and not need_y) else None)
         ctx.g_ref, ctx.b_ref = gamma, beta
         ctx.cfg = (act, slope, residual is not None)
         ctx.mark_non_differentiable(stats)
@@ -228,7 +230,7 @@ class _BatchNormTrain(Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
-        x, gamma, stats, y = ctx.saved_tensors
+        x, gamma, stats, y, beta = ctx.saved_tensors
         act, slope, has_res = ctx.cfg
         dy = _c(dy)
         N, C, H, W = x.shape
@@ -248,7 +250,7 @@ class _BatchNormTrain(Function):
         if has_res and ctx.needs_input_grad[3]:
             dres = torch.empty_like(x) if act else dy
         ws = _lib.workspace(x.device, C * 128)
-        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(dx),
+        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx),
              ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
              N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
@@ -298,13 +300,13 @@ class _InstanceNorm(Function):
         ws = _lib.workspace(x.device, N * C * 128)
         call("instancenorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats[0]), ptr(stats[1]), N, C, H * W, eps, act, slope,
              ptr(ws), stream_ptr())
-        ctx.save_for_backward(x, gamma, stats, y if act else None)
+        ctx.save_for_backward(x, gamma, stats, y if act == ACT_TANH else None, beta if act and act != ACT_TANH else None)
         ctx.cfg = (act, slope)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, stats, y = ctx.saved_tensors
+        x, gamma, stats, y, beta = ctx.saved_tensors
         act, slope = ctx.cfg
         dy = _c(dy)
         N, C, H, W = x.shape
@@ -312,7 +314,7 @@ class _InstanceNorm(Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
         ws = _lib.workspace(x.device, N * C * 128)
-        call("instancenorm_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(dx), ptr(dgamma), ptr(dbeta),
+        call("instancenorm_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx), ptr(dgamma), ptr(dbeta),
              N, C, H * W, act, slope, ptr(ws), stream_ptr())
         return dx, dgamma, dbeta, None, None, None
 

@@ -88,8 +88,10 @@ int faoctasr_batchnorm_train_fwd(const float* x, const float* gamma, const float
                                  float* workspace, faoctasr_stream_t stream);
 /* dx overwritten; dgamma[C], dbeta[C] overwritten or (accumulate_affine != 0) added to; y is
  * the saved forward output (activation mask); the residual gradient dy*act'(y) is written to
- * dres when dres != NULL.                                                                 */
-int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+ * dres when dres != NULL.  y may be NULL for act NONE / RELU / LRELU when the forward had NO residual: the mask is then taken
+ * from the recomputed pre-activation x*gamma*invstd + (beta - mean*gamma*invstd) (the forward's own expression), which saves
+ * one tensor read per pass; `beta` is only read in that case.                                */
+int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                                  const float* save_mean, const float* save_invstd,
                                  float* dx, float* dgamma, float* dbeta, float* dres,
                                  int N, int C, int HW, int act, float slope, int accumulate_affine,
@@ -106,7 +108,7 @@ int faoctasr_batchnorm_eval_bwd(const float* dy, const float* y, const float* ga
 int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                               float* save_mean, float* save_invstd, int N, int C, int HW, float eps,
                               int act, float slope, float* workspace, faoctasr_stream_t stream);
-int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                               const float* save_mean, const float* save_invstd, float* dx,
                               float* dgamma, float* dbeta, int N, int C, int HW, int act, float slope,
                               float* workspace, faoctasr_stream_t stream);
