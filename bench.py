@@ -6,11 +6,17 @@ N=1: BASELINE.json configs[1] (256x256x1, batch 8, fp32, 1 MI355X).  N>1 (launch
 torch.distributed.run, one rank per GPU): the same per-GPU batch on every rank (weak scaling), gradients of the two
 flat arenas all-reduced over RCCL per optimizer phase.  Rank 0 prints ONE JSON line.
 
+Plain `python bench.py --gpus N` (no launcher) spawns the N ranks itself before touching the GPU.
+
 Beside the headline value the line carries
-  roofline:     the dominant kernel (the implicit-GEMM gather kernel = conv forward + input-gradient) timed with HIP
-                events on the launch stream over extra steps of the same workload: algorithmic FLOP / measured time
-                against the f32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline: the CPU oracle (oracle/octa_oracle.py, kind "port") timed on this box's host cores on a bounded sample.
+  roofline:           the dominant convolution kernel family BY TIME (HIP events on the launch stream around every
+                      convolution-type C-ABI call over extra steps of the same workload, tagged with the kernel family the
+                      dispatcher chose): algorithmic FLOP / measured time against the f32 MFMA peak (157.3 TFLOP/s), plus
+                      the executed-FLOP fraction and, when profiles/r02_*.json exist, rocprofv3's MFMA-busy share and HBM bytes;
+  roofline_families:  the same for every family (winograd, patch, gather_flat, wgrad_s1, wgrad_patch, wgrad_flat, ...);
+  roofline_hbm:       Haar DWT / SSIM kernels, forward and backward, against the 8 TB/s HBM peak;
+  cpu_baseline:       the CPU oracle (oracle/octa_oracle.py, kind "port") on this box's host cores, bounded sample, with
+                      cached masks (value) and with the reference's per-call Python mask loops (reference_style_masks).
 """
 import argparse
 import json
@@ -50,19 +56,47 @@ def conv_flops(name, a):
     return 2.0 * N * C * IH * IW * M * KH * KW          # transposed: every input pixel meets every tap
 
 
+ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad"}
+KERNEL_OF = {"gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps narrower than 24)",
+             "patch": "igemm_patch_kernel (LDS-patch implicit GEMM: 7x7, stride-2, transposed phases)",
+             "winograd": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3 forward + input gradient)",
+             "bf16x3": "igemm_bf16x3_kernel (hi/lo-split operands on v_mfma_f32_32x32x16_bf16)",
+             "m1_head": "conv_m1_fwd_kernel (64 -> 1 head, VALU)",
+             "wgrad_flat": "igemm_wgrad_kernel (flat weight gradient, narrow maps)",
+             "wgrad_patch": "wgrad_patch_kernel (LDS-patch weight gradient: stride 2, ragged shapes)",
+             "wgrad_s1": "wgrad_s1_kernel (stride-1 weight gradient, staging pipelined inside the MFMA loop)",
+             "m1_wgrad": "conv_m1_wgrad_kernel (64 -> 1 head, VALU)"}
+#: share of the algorithmic (direct-convolution) FLOP a family really executes on the matrix pipe
+EXECUTED = {"winograd": 16.0 / 36.0}
+
+
 class LaunchTimer:
+    """HIP events (torch.cuda.Event on the launch stream = torch's current stream) around every convolution-type C-ABI call,
+    tagged with the kernel family the dispatcher chose (faoctasr_last_route)."""
+
     def __init__(self, names):
         self.names = set(names)
         self.rec = []
 
-    def add(self, name, args, s, e):
-        self.rec.append((name, conv_flops(name, args), s, e))
+    def add(self, name, args, s, e, route):
+        self.rec.append((ROUTES.get(route, "route%d" % route), conv_flops(name, args), s, e))
 
-    def summary(self, group):
-        ms = sum(s.elapsed_time(e) for n, f, s, e in self.rec if n in group)
-        fl = sum(f for n, f, s, e in self.rec if n in group)
-        cnt = sum(1 for n, f, s, e in self.rec if n in group)
-        return ms, fl, cnt
+    def families(self, nsteps):
+        out = {}
+        for fam, fl, s, e in self.rec:
+            d = out.setdefault(fam, {"ms": 0.0, "flop": 0.0, "launches": 0})
+            d["ms"] += s.elapsed_time(e)
+            d["flop"] += fl
+            d["launches"] += 1
+        res = {}
+        for fam, d in out.items():
+            tf = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            ex = EXECUTED.get(fam, 1.0)
+            res[fam] = {"kernel": KERNEL_OF.get(fam, fam), "launches_per_step": d["launches"] // nsteps, "ms_per_step": round(d["ms"] / nsteps, 3),
+                        "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3),
+                        "tflops_algorithmic": round(tf, 2), "frac_algorithmic": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                        "tflops_executed": round(tf * ex, 2), "frac_executed": round(tf * ex / F32_MFMA_PEAK_TFLOPS, 4)}
+        return res
 
 
 def make_batch(B, H, device, rank):
@@ -74,7 +108,9 @@ def make_batch(B, H, device, rank):
 
 def cpu_baseline(H, budget_s=15.0):
     """The CPU oracle on the host cores, bounded: batch-2 steps (per-image work identical to the workload) after one untimed
-    warm-up step, repeated until ~budget_s seconds of timed CPU work have accumulated."""
+    warm-up step, repeated until ~budget_s seconds of timed CPU work have accumulated.  Two legs: masks of
+    the frequency split cached / vectorised (the headline `value`), and built per call by a Python double loop the way the
+    reference does (utils.py:71-91) -- `reference_style_masks`."""
     from oracle import octa_oracle as O
     nt = host_threads()
     torch.set_num_threads(nt)
@@ -82,23 +118,37 @@ def cpu_baseline(H, budget_s=15.0):
     B = 2
     a, b = O.synthetic_batch(B, H)
     S.train_step(a, b)
-    steps, total = 0, 0.0
-    while total < budget_s and steps < 8:
-        t0 = time.time()
-        S.train_step(a, b)
-        total += time.time() - t0
-        steps += 1
-    return {"value": round(B * steps / total, 4), "unit": "images/s", "cores": nt, "kind": "port",
-            "sample": "CPU oracle (oracle/octa_oracle.py): %d timed %dx%d batch-%d fp32 train steps after 1 warm-up, %d torch threads, %.1f s of CPU work"
-                      % (steps, H, H, B, nt, total)}
+
+    def leg(budget, max_steps):
+        steps, total = 0, 0.0
+        while total < budget and steps < max_steps:
+            t0 = time.time()
+            S.train_step(a, b)
+            total += time.time() - t0
+            steps += 1
+        return steps, total
+
+    steps, total = leg(budget_s, 8)
+    out = {"value": round(B * steps / total, 4), "unit": "images/s", "cores": nt, "kind": "port",
+           "sample": "CPU oracle (oracle/octa_oracle.py): %d timed %dx%d batch-%d fp32 train steps after 1 warm-up, %d torch threads, %.1f s of CPU work"
+                     % (steps, H, H, B, nt, total)}
+    O.MASK_STYLE = "loop"
+    try:
+        steps2, total2 = leg(budget_s * 0.6, 2)
+    finally:
+        O.MASK_STYLE = "vectorised"
+    out["reference_style_masks"] = {"value": round(B * steps2 / total2, 4), "unit": "images/s",
+                                    "sample": "same step with the Gaussian masks rebuilt per call by the reference's Python double loop "
+                                              "(utils.py:71-91): %d timed steps, %.1f s" % (steps2, total2)}
+    return out
 
 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def hbm_kernels(device, images=512, H=256):
-    """HBM roofline lines of the frequency-path kernels north_star names (Haar DWT level, SSIM window): algorithmic bytes
-     / HIP-event time on `images` 256x256 planes (134 MB per tensor, far beyond the 256 MB MALL for the pair)."""
+    """HBM roofline lines of the frequency-path kernels north_star names (Haar DWT level, SSIM window), forward and backward:
+    algorithmic bytes / HIP-event time on `images` 256x256 planes (134 MB per tensor, beyond the 256 MB MALL for a pair)."""
     from faoctasr import ops
     g = torch.Generator(device="cpu").manual_seed(7)
     a = torch.rand(images, 1, H, H, generator=g).to(device)
@@ -116,20 +166,25 @@ def hbm_kernels(device, images=512, H=256):
         torch.cuda.synchronize()
         return s.elapsed_time(e) / n * 1e-3
 
+    ll, hi = ops.haar_afb2d(a)
+    gsum = torch.ones(images, device=device)
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    dxh = torch.empty_like(a)
+    from faoctasr._lib import call, ptr, stream_ptr
+    cases = (("haar_dwt2d_fwd (DWTForward level, AFB2D)", lambda: ops.haar_afb2d(a), 2 * plane),
+             ("haar_dwt2d_bwd (AFB2D backward = SFB2D synthesis)",
+              lambda: call("haar_dwt2d_bwd", ptr(ll), ptr(hi), ptr(dxh), images, H, H, stream_ptr()), 2 * plane),
+             ("ssim_fwd (11x11 Gaussian window SSIM, per-image sums)", lambda: ops.ssim(a, b), 2 * plane),
+             ("ssim_bwd (gradient of the SSIM mean w.r.t. both images)",
+              lambda: call("ssim_bwd", ptr(a), ptr(b), ptr(gsum), images, 1.0, ptr(da), ptr(db), images, 1, H, H, stream_ptr()), 4 * plane))
     out = []
     with torch.no_grad():
-        for name, fn, nbytes in (("haar_dwt2d_fwd (DWTForward level, AFB2D)", lambda: ops.haar_afb2d(a), 2 * plane),
-                                 ("ssim_fwd (11x11 Gaussian window SSIM mean)", lambda: ops.ssim(a, b), 2 * plane)):
+        for name, fn, nbytes in cases:
             t = timed(fn)
             gbs = nbytes / t / 1e9
             out.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes, "us": round(t * 1e6, 1),
                         "sample": "%d planes of %dx%d fp32" % (images, H, H)})
-            if name.startswith("ssim"):
-                # two 11-tap passes over five moment maps: ~270 FLOP per pixel against 8 bytes (34 FLOP/B, above the machine
-                # balance of ~20): the window kernel is bound by the fp32 vector pipe, not by HBM
-                fl = 270.0 * images * H * H
-                out[-1]["note"] = "VALU-bound (34 FLOP/B): %.1f TFLOP/s of the 157.3 TFLOP/s packed-fp32 vector peak" % (fl / t / 1e12)
     return out
 
 
@@ -229,27 +284,38 @@ def main():
         torch.cuda.synchronize()
         _lib.launch_timer = None
     if rank == 0 and not args.no_roofline:
-        ms, fl, cnt = timer.summary(GATHER)
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("igemm_gather_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"bound": "mfma", "kernel": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3) + igemm_patch_kernel + igemm_gather_kernel: conv forward + input gradient on the "
-                          "f32 MFMA; achieved = direct-convolution (algorithmic) FLOP / time"
-                if args.precision == "f32" else "igemm_bf16x3_kernel (+ f32 kernels on narrow maps), f32-equivalent FLOP", "achieved": round(ach, 2),
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "launches_per_step": cnt // nroof, "avg_launch_us": round(1e3 * ms / cnt, 2),
-                "gflop_per_launch": round(fl / cnt / 1e9, 3)}
-        ms2, fl2, cnt2 = timer.summary(WGRAD)
-        extra["roofline_wgrad"] = {"bound": "mfma", "kernel": "wgrad_patch_kernel + igemm_wgrad_kernel (weight gradients, v_mfma_f32_32x32x2_f32)", "achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 2),
-                                   "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl2 / (ms2 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-                                   "launches_per_step": cnt2 // nroof, "avg_launch_us": round(1e3 * ms2 / cnt2, 2)}
-        extra["conv_ms_per_step"] = round((ms + ms2) / nroof, 2)
-        extra["conv_tflop_per_step"] = round((fl + fl2) / nroof / 1e12, 3)
+        fams = timer.families(nroof)
+        prof = {}
+        for fn in ("r02_mfma_utilisation.json", "r02_traffic.json"):           # rocprofv3 --pmc summaries of this same command
+            fp = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(fp):
+                try:
+                    prof[fn] = json.load(open(fp)).get("families", {})
+                except Exception:
+                    prof[fn] = {}
+        for fam, d in fams.items():
+            busy = prof.get("r02_mfma_utilisation.json", {}).get(fam, {}).get("mfma_busy_frac")
+            if busy is not None:
+                d["mfma_busy_frac_rocprof"] = busy
+            d["hbm_bytes_per_launch_rocprof"] = prof.get("r02_traffic.json", {}).get(fam, {}).get("hbm_bytes_per_launch")
+        dom = max(fams, key=lambda k: fams[k]["ms_per_step"])                 # the dominant kernel family BY TIME
+        d = fams[dom]
+        roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": d["tflops_algorithmic"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": d["frac_algorithmic"], "traffic": d["hbm_bytes_per_launch_rocprof"], "family": dom,
+                "definition": "achieved = algorithmic (direct-convolution) FLOP of the family's launches / their HIP-event time; "
+                              "frac_executed counts the FLOP the matrix pipe really runs (Winograd: 16/36 of the algorithmic); "
+                              "peak = exact-fp32 MFMA at 2.4 GHz -- under this load the chip holds ~2.05-2.1 GHz (DESIGN.md 5)",
+                "frac_executed": d["frac_executed"], "mfma_busy_frac_rocprof": d.get("mfma_busy_frac_rocprof"),
+                "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_launch_us"], "gflop_per_launch": d["gflop_per_launch"],
+                "ms_per_step": d["ms_per_step"]}
+        extra["roofline_families"] = fams
+        tot_ms = sum(v["ms_per_step"] for v in fams.values())
+        tot_fl = sum(v["gflop_per_launch"] * v["launches_per_step"] for v in fams.values()) / 1e3
+        extra["conv_ms_per_step"] = round(tot_ms, 2)
+        extra["conv_tflop_per_step"] = round(tot_fl, 3)
+        extra["conv_tflop_note"] = ("BASELINE.md quotes 1.566 TFLOP per image-step (12.53 at batch 8); its hook count includes every discriminator "
+                                    "convolution twice (41.8 GMAC per image: D forward 31.4 -> 15.7, D input gradient 10.5 -> 5.2, D-step backward "
+                                    "41.9 -> 20.9; per-layer table in DESIGN.md 5.2), so the step's algorithmic work is 1.482 TFLOP per image")
     # secondary measurement (never the headline): the same step with the opt-in bf16x3 contraction
     if rank == 0 and not distributed and args.precision == "f32" and not args.no_alt:
         ts.precision = "bf16x3"

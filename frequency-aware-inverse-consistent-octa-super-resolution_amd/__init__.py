@@ -8,7 +8,7 @@ from . import _lib, ops
 from ._lib import KernelError
 from .model import (Discriminator, FS_DiscriminatorA, FS_DiscriminatorB, NetworkA2B, NetworkB2A, ResidualBlock, ResnetBlock,
                     ResnetGenerator, TVLoss, UnetGenerator, UnetSkipConnectionBlock, shallowNet)
-from .evaluate import evaluate_pairs, super_resolve
+from .evaluate import evaluate_pairs, image_metrics, super_resolve
 from . import ssim                # stays the MODULE: the reference does `import ssim; ssim.SSIM()` (train.py:24,97)
 from .ssim import SSIM
 from .ssim import ssim as ssim_fn  # the function ssim.py:65-73; not exported under the submodule's name

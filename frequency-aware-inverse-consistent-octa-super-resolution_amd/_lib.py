@@ -15,6 +15,7 @@ _SIG = {
     # name: (restype, "argument codes")   p pointer, i int, l long, f float
     "version": (_I, ""),
     "last_error": (ctypes.c_char_p, ""),
+    "last_route": (_I, ""),
     "conv_wpack_floats": (_L, "iiiiiiii"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
@@ -55,6 +56,9 @@ _SIG = {
     "prep_crop_resize": (_I, "pppp iiiii ff p"),
     "fill": (_I, "p l f p"),
     "circulant_lowpass": (_I, "p i f p"),
+    "eval_workspace_bytes": (_L, "ii"),
+    "eval_metrics": (_I, "pppp iii f i p"),
+    "bn_fold": (_I, "pppppp f pp i l i l p"),
     "comm_unique_id": (_I, "p"),
     "comm_create": (_I, "p ii p"),
     "comm_destroy": (_I, "p"),
@@ -119,7 +123,7 @@ def call(name, *args):
         s.record()
         rc = getattr(lib, "faoctasr_" + name)(*args)
         e.record()
-        t.add(name, args, s, e)
+        t.add(name, args, s, e, lib.faoctasr_last_route())
     else:
         rc = getattr(lib, "faoctasr_" + name)(*args)
     if rc != 0:

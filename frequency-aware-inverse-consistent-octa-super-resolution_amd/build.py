@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "wgrad_patch.hip", "wgrad_s1.hip", "conv_m1.hip", "pointwise.hip", "norm.hip", "sgemm.hip",
-           "ssim.hip", "comm.hip"]
+           "ssim.hip", "eval.hip", "comm.hip"]
 HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(ROOT, "include", "faoctasr.h")]
 LIB = os.path.join(HERE, "libfaoctasr.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")

@@ -454,11 +454,11 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
     if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     if (wpack && wpack_state && precision == 2) {
         const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_BF16X3); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state && precision == 0) {
         const int rc = wino_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_WINOGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state) {
         PatchGeom pg;
@@ -469,8 +469,9 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
             if (rc) return rc;
         }
         rc = launch_patch(x, wpack, bias, y, pg, act, slope, s);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_PATCH); return rc < 0 ? rc : FAOCTASR_OK; }
     }
+    set_route(ROUTE_GATHER_FLAT);
     return launch_gather(x, w, bias, y, g, act, slope, s);
 }
 
@@ -520,7 +521,10 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: kernel (%d x %d) larger than padded input (%d x %d)", KH, KW, IH + 2 * pad, IW + 2 * pad);
     if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
+    {
+        set_route(ROUTE_M1_FWD);
         return launch_conv_m1_fwd(x, w, bias, y, N, C, IH, IW, KH, KW, pad, act, slope, (hipStream_t)stream);
+    }
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
@@ -545,7 +549,10 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");
     if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
+    {
+        set_route(ROUTE_M1_WGRAD);
         return launch_conv_m1_wgrad(x, dy, dw, N, C, IH, IW, KH, KW, pad, accumulate, (hipStream_t)stream);
+    }
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
@@ -554,12 +561,14 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
             return fail(FAOCTASR_EHIP, "memset dw failed");
         rc = launch_wgrad_s1(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
                              (hipStream_t)stream);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_WGRAD_S1); return rc < 0 ? rc : FAOCTASR_OK; }
         rc = launch_wgrad_patch(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
                                 (hipStream_t)stream);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_WGRAD_PATCH); return rc < 0 ? rc : FAOCTASR_OK; }
+        set_route(ROUTE_WGRAD_FLAT);
         return launch_wgrad(x, dy, dw, g, (long)M * C * KH * KW, 1, (hipStream_t)stream);
     }
+    set_route(ROUTE_WGRAD_FLAT);
     return launch_wgrad(x, dy, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
 }
 
@@ -601,9 +610,11 @@ int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, 
             return fail(FAOCTASR_EHIP, "memset dw failed");
         rc = launch_wgrad_patch(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,
                                 (hipStream_t)stream);
-        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+        if (rc != 0) { set_route(ROUTE_WGRAD_PATCH); return rc < 0 ? rc : FAOCTASR_OK; }
+        set_route(ROUTE_WGRAD_FLAT);
         return launch_wgrad(dy, x, dw, g, (long)M * C * KH * KW, 1, (hipStream_t)stream);
     }
+    set_route(ROUTE_WGRAD_FLAT);
     return launch_wgrad(dy, x, dw, g, (long)M * C * KH * KW, accumulate, (hipStream_t)stream);
 }
 

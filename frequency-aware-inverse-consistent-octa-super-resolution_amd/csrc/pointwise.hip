@@ -9,6 +9,7 @@ namespace faoctasr {
 
 thread_local char g_err[512] = "";
 char* err_buf() { return g_err; }
+int get_route();
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -16,6 +17,10 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+thread_local int g_route = 0;
+void set_route(int r) { g_route = r; }
+int get_route() { return g_route; }
 
 void lds_optin(const void* kernel, size_t lds_bytes) {
     if (lds_bytes <= 64 * 1024) return;
@@ -462,6 +467,7 @@ extern "C" {
 
 int faoctasr_version(void) { return 200; }
 const char* faoctasr_last_error(void) { return err_buf(); }
+int faoctasr_last_route(void) { return faoctasr::get_route(); }
 
 int faoctasr_batchnorm_eval_fwd(const float* x, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                 float* y, int N, int C, int HW, float eps, int act, float slope, faoctasr_stream_t stream) {

@@ -1,17 +1,16 @@
-"""Inference / evaluation path of the reference (utils.py:182-242 `eval`, `eval_6m`).
+"""Inference / evaluation path of the reference (utils.py:182-242 `eval`, `eval_6m`), on the device.
 
-``super_resolve`` is the reference's inference recipe (utils.py:202-205): frequency split with radii (10, 8), generator
-forward in eval mode (BatchNorm on running statistics, executed by the HIP kernels).  ``evaluate_pairs`` reproduces the
-metric loop: like the reference it moves each output to the host and scores it there; skimage is not available offline, so
-the four skimage metrics are restated in numpy from their published definitions (defaults of the calls at utils.py:209-212).
-Dataset / PNG IO is out of scope: the caller supplies tensors.
+``super_resolve`` is the reference's inference recipe (utils.py:202-205): frequency split with radii (10, 8), generator forward
+in eval mode.  `model.eval()` turns every BatchNorm2d into a per-channel affine map; the forward folds it into the preceding
+convolution's weights (``faoctasr_bn_fold``), so the inference generator is convolutions + activations only.
+``image_metrics`` / ``evaluate_pairs`` score outputs with the four skimage metrics of utils.py:209-212 -- PSNR, SSIM (7x7 uniform
+window), MSE, NMI (100 x 100 joint histogram) -- computed by HIP kernels (``faoctasr_eval_metrics``); the reference copies every
+image to the host for skimage.  Only the N x 4 results travel.  Dataset / PNG IO is out of scope: the caller supplies tensors.
 """
-import math
-
-import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
+from ._lib import call, ptr, stream_ptr
 
 
 @torch.no_grad()
@@ -22,53 +21,36 @@ def super_resolve(model, lr_img, r_hp=10, r_lp=8):
     return model(lf, hf)[2]
 
 
-def psnr(y, gt, data_range=2.0):
-    """skimage.metrics.peak_signal_noise_ratio = 10 log10(data_range^2 / MSE)."""
-    err = float(np.mean((np.asarray(y, np.float64) - np.asarray(gt, np.float64)) ** 2))
-    return 10.0 * math.log10(data_range ** 2 / err)
-
-
-def mse(y, gt):
-    return float(np.mean((np.asarray(y, np.float64) - np.asarray(gt, np.float64)) ** 2))
-
-
-def nmi(a, b, bins=100):
-    """skimage.metrics.normalized_mutual_information: (H(a) + H(b)) / H(a, b), entropies (natural log... base cancels) of the
-    joint ``bins`` x ``bins`` histogram and its marginals."""
-    h, _, _ = np.histogram2d(np.ravel(a), np.ravel(b), bins=bins)
-    def ent(p):
-        p = p[p > 0] / p.sum()
-        return float(-(p * np.log(p)).sum())
-    return (ent(h.sum(1)) + ent(h.sum(0))) / ent(h.ravel())
-
-
-def ssim_skimage(a, b, data_range=2.0, win=7):
-    """skimage.metrics.structural_similarity defaults for 2-D float images: 7x7 uniform window, K1 0.01, K2 0.03, sample
-    covariance, mean over the map cropped by (win-1)/2."""
-    from scipy.ndimage import uniform_filter
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    NP = win * win
-    cov_norm = NP / (NP - 1.0)
-    ux, uy = uniform_filter(a, win), uniform_filter(b, win)
-    uxx, uyy, uxy = uniform_filter(a * a, win), uniform_filter(b * b, win), uniform_filter(a * b, win)
-    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
-    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
-    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
-    p = (win - 1) // 2
-    return float(S[p:-p, p:-p].mean())
+@torch.no_grad()
+def image_metrics(y, gt, data_range=2.0, bins=100):
+    """y, gt: (N,1,H,W) or (N,H,W) device tensors -> float64 tensor (N,4) on the device: PSNR, SSIM, MSE, NMI per image pair
+    (skimage.metrics.peak_signal_noise_ratio(data_range=2) / structural_similarity / mean_squared_error /
+    normalized_mutual_information with their defaults, utils.py:209-212)."""
+    y, gt = ops._c(y), ops._c(gt)
+    if y.shape != gt.shape:
+        raise _lib.KernelError("image_metrics: shapes differ: %s vs %s" % (tuple(y.shape), tuple(gt.shape)))
+    if y.dim() == 4:
+        if y.shape[1] != 1:
+            raise _lib.KernelError("image_metrics: single-channel images expected")
+        N, _, H, W = y.shape
+    else:
+        N, H, W = y.shape
+    out = torch.empty((N, 4), dtype=torch.float64, device=y.device)
+    nbytes = _lib.load().faoctasr_eval_workspace_bytes(N, bins)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=y.device)
+    call("eval_metrics", ptr(y), ptr(gt), out.data_ptr(), ws.data_ptr(), N, H, W, float(data_range), int(bins), stream_ptr())
+    return out
 
 
 def evaluate_pairs(model, pairs):
-    """pairs: iterable of (lr (1,1,H,W), hr (1,1,H,W)) device tensors.  Returns mean PSNR / SSIM / MSE / NMI like the print
-    at utils.py:214,242."""
-    tot = {"psnr": 0.0, "ssim": 0.0, "mse": 0.0, "nmi": 0.0}
-    n = 0
+    """pairs: iterable of (lr (B,1,H,W), hr (B,1,H,W)) device tensors.  Returns mean PSNR / SSIM / MSE / NMI like the print at
+    utils.py:214,242; one host read at the end."""
+    acc, n = None, 0
     for lr, hr in pairs:
-        y = super_resolve(model, lr).cpu().numpy().squeeze(0).squeeze(0)
-        g = hr.cpu().numpy().squeeze(0).squeeze(0)
-        tot["psnr"] += psnr(y, g, 2.0)
-        tot["ssim"] += ssim_skimage(y, g, 2.0)
-        tot["mse"] += mse(y, g)
-        tot["nmi"] += nmi(y, g)
-        n += 1
-    return {k: v / max(n, 1) for k, v in tot.items()}
+        m = image_metrics(super_resolve(model, lr), hr).sum(0)
+        acc = m if acc is None else acc + m
+        n += lr.shape[0]
+    if acc is None:
+        return {"psnr": 0.0, "ssim": 0.0, "mse": 0.0, "nmi": 0.0}
+    vals = (acc / n).tolist()
+    return dict(zip(("psnr", "ssim", "mse", "nmi"), vals))

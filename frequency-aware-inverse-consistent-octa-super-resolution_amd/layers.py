@@ -11,6 +11,28 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import call, ptr, stream_ptr
+
+
+def folded_conv_params(conv, bn):
+    """(weight, bias) of ``conv`` with the eval-mode BatchNorm ``bn`` folded in (``faoctasr_bn_fold``): what `model.eval()`
+    (utils.py:186) turns conv -> BN into.  Cached on the conv module until its weights or the BN's statistics change."""
+    key = (conv.weight._version, conv.weight.data_ptr(), ops.weight_epoch, bn.weight._version, bn._stat_epoch,
+           None if conv.bias is None else conv.bias._version)
+    hit = getattr(conv, "_folded", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    w = conv.weight.detach()
+    wf = torch.empty_like(w)
+    bf = torch.empty(bn.num_features, dtype=torch.float32, device=w.device)
+    transposed = isinstance(conv, ConvTranspose2d)
+    M = conv.out_channels
+    kk = conv.kernel_size * conv.kernel_size
+    call("bn_fold", ptr(w), ptr(conv.bias.detach()) if conv.bias is not None else None, ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+         ptr(bn.running_mean), ptr(bn.running_var), bn.eps, ptr(wf), ptr(bf), M, kk if transposed else conv.in_channels * kk,
+         1 if transposed else 0, conv.in_channels if transposed else 1, stream_ptr())
+    conv._folded = (key, wf, bf)
+    return wf, bf
 
 
 class Conv2d(nn.Module):
@@ -30,10 +52,11 @@ class Conv2d(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x, act=None, slope=0.2, reflect_pad=0):
+    def forward(self, x, act=None, slope=0.2, reflect_pad=0, params=None):
+        w, b = params if params is not None else (self.weight, self.bias)
         if reflect_pad:
-            return ops.conv2d(x, self.weight, self.bias, self.stride, reflect_pad, True, act, slope)
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, act, slope)
+            return ops.conv2d(x, w, b, self.stride, reflect_pad, True, act, slope)
+        return ops.conv2d(x, w, b, self.stride, self.padding, False, act, slope)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d, padding=%d, bias=%s" % (
@@ -53,8 +76,9 @@ class ConvTranspose2d(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x, act=None, slope=0.2):
-        return ops.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope)
+    def forward(self, x, act=None, slope=0.2, params=None):
+        w, b = params if params is not None else (self.weight, self.bias)
+        return ops.conv_transpose2d(x, w, b, self.stride, self.padding, self.output_padding, act, slope)
 
 
 class BatchNorm2d(nn.Module):
@@ -71,6 +95,7 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0
+        self._stat_epoch = 0          # bumped whenever the running statistics change (they change through raw pointers)
 
     def _flush_counter(self):
         if self._pending_batches:
@@ -83,6 +108,7 @@ class BatchNorm2d(nn.Module):
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._pending_batches = 0
+        self._stat_epoch += 1
         super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x, act=None, slope=0.2, residual=None):
@@ -95,6 +121,7 @@ class BatchNorm2d(nn.Module):
                     y = ops.activation(y, act, slope)
             return y
         self._pending_batches += 1
+        self._stat_epoch += 1
         return ops.batchnorm_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
                                    residual)
 
@@ -166,11 +193,29 @@ class FusedSequential(nn.Sequential):
             nxt = mods[i + 1] if i + 1 < n else None
             if isinstance(m, ReflectionPad2d) and isinstance(nxt, Conv2d) and nxt.padding == 0:
                 after = mods[i + 2] if i + 2 < n else None
+                if isinstance(after, BatchNorm2d) and not after.training and not torch.is_grad_enabled():
+                    act = mods[i + 3] if i + 3 < n else None
+                    if isinstance(act, _ACTS):
+                        x = nxt(x, act=act.act, slope=act.slope, reflect_pad=m.padding, params=folded_conv_params(nxt, after))
+                        i += 4
+                    else:
+                        x = nxt(x, reflect_pad=m.padding, params=folded_conv_params(nxt, after))
+                        i += 3
+                    continue
                 if isinstance(after, (LeakyReLU, Tanh)):
                     x = nxt(x, act=after.act, slope=after.slope, reflect_pad=m.padding)
                     i += 3
                 else:
                     x = nxt(x, reflect_pad=m.padding)
+                    i += 2
+            elif isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(nxt, BatchNorm2d) and not nxt.training and not torch.is_grad_enabled():
+                # inference: conv -> BN(eval) [-> act] is ONE convolution with folded weights (utils.py:186 `model.eval()`)
+                after = mods[i + 2] if i + 2 < n else None
+                if isinstance(after, _ACTS):
+                    x = m(x, act=after.act, slope=after.slope, params=folded_conv_params(m, nxt))
+                    i += 3
+                else:
+                    x = m(x, params=folded_conv_params(m, nxt))
                     i += 2
             elif isinstance(m, (Conv2d, ConvTranspose2d)):
                 if isinstance(nxt, _ACTS):

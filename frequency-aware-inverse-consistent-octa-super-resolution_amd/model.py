@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import (BatchNorm2d, Conv2d, ConvTranspose2d, FusedSequential, LeakyReLU, ReflectionPad2d, ReLU, Tanh)
+from .layers import (BatchNorm2d, Conv2d, ConvTranspose2d, FusedSequential, LeakyReLU, ReflectionPad2d, ReLU, Tanh, folded_conv_params)
 from .wavelets import DWTForward
 
 
@@ -232,6 +232,10 @@ class _ResBlock(nn.Module):
 
     def forward(self, x, post_act=None):
         cb = self.conv_block
+        if not cb[1].training and not torch.is_grad_enabled():       # inference: both BatchNorms folded into their convolutions
+            y = cb[0](x, act="relu", params=folded_conv_params(cb[0], cb[1]))
+            y = ops.add(cb[3](y, params=folded_conv_params(cb[3], cb[4])), x)
+            return ops.activation(y, post_act) if post_act else y
         y = cb[1](cb[0](x), act="relu")
         return cb[4](cb[3](y), act=post_act, residual=x)
 

@@ -26,6 +26,10 @@ enum { FAOCTASR_OK = 0, FAOCTASR_EINVAL = -1, FAOCTASR_EUNSUPPORTED = -2, FAOCTA
 
 int faoctasr_version(void);
 const char* faoctasr_last_error(void);
+/* diagnostics (bench.py's per-family roofline): the kernel family the calling thread's last convolution-type call went to:
+ * 1 flat implicit GEMM (narrow maps), 2 LDS-patch implicit GEMM, 3 Winograd F(2x2,3x3), 4 bf16x3 split, 5 M=1 head (VALU);
+ * 11 flat weight gradient, 12 LDS-patch weight gradient, 13 stride-1 weight gradient (wgrad_s1), 14 M=1 weight gradient   */
+int faoctasr_last_route(void);
 
 /* ---- convolution family (implicit GEMM on f32 MFMA) --------------------------------------
  * nn.Conv2d forward: model.py:102,109,117,122 (discriminator), 242-244,250,258,275-277,286
@@ -212,6 +216,21 @@ int faoctasr_comm_size(void* comm);                 /* number of ranks (> 0) or 
 int faoctasr_grad_allreduce(float* bucket, long count, int dtype, void* comm, faoctasr_stream_t stream);
 /* identical replicas at start: rank `root`'s parameter arena / BatchNorm buffers to everyone, in place */
 int faoctasr_param_broadcast(float* buf, long count, int root, void* comm, faoctasr_stream_t stream);
+
+/* ---- evaluation path: utils.py:182-242 `eval` / `eval_6m` ------------------------------------------------------
+ * The four skimage metrics of utils.py:209-212 on device images: y, gt [N][H][W] fp32; out [N][4] doubles = {PSNR
+ * (peak_signal_noise_ratio, data_range), SSIM (structural_similarity defaults: 7x7 uniform window, sample covariance, map cropped
+ * by 3), MSE, NMI (normalized_mutual_information: joint bins x bins histogram over each image's [min, max], numpy.histogram2d
+ * bin semantics)}.  data_range = 2, bins = 100 reproduce the reference.  workspace: faoctasr_eval_workspace_bytes(N, bins) bytes. */
+long faoctasr_eval_workspace_bytes(int N, int bins);
+int faoctasr_eval_metrics(const float* y, const float* gt, double* out, void* workspace, int N, int H, int W, float data_range, int bins,
+                          faoctasr_stream_t stream);
+/* `model.eval()` (utils.py:186,221) makes every BatchNorm2d a per-channel affine map; folded into the preceding convolution:
+ * w_folded = w * gamma / sqrt(running_var + eps) per output channel m, bias_folded = (bias - running_mean) * that + beta.
+ * w is [M][K] (Conv2d; transposed = 0) or [K0][M][K] (ConvTranspose2d weight [C][M][kh*kw]; transposed = 1).            */
+int faoctasr_bn_fold(const float* w, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, float* w_folded, float* bias_folded, int M, long K, int transposed, long K0,
+                     faoctasr_stream_t stream);
 
 /* ---- utility ---------------------------------------------------------------------------------- */
 int faoctasr_fill(float* p, long n, float value, faoctasr_stream_t stream);

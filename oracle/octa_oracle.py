@@ -112,17 +112,39 @@ def gauss_mask(rows, cols, radius, high):
     return torch.from_numpy(m).float()
 
 
+#: "vectorised" (default) builds the mask with numpy broadcasting; "loop" builds it the way the reference does on EVERY call
+#: (utils.py:71-91: a Python double loop over rows x cols into a complex array) -- same values, ~1 s per 256x256 train step.
+#: bench.py times both forms of the CPU baseline.
+MASK_STYLE = "vectorised"
+
+
+def gauss_mask_loop(rows, cols, radius, high):
+    """utils.py:71-80 (guais_low_pass) / 82-91 (guais_high_pass) as written: per-element Python arithmetic, complex mask."""
+    center = int(rows / 2), int(cols / 2)
+    mask = np.zeros((rows, cols), dtype=complex)
+    for i in range(rows):
+        for j in range(cols):
+            d = (i - center[0]) ** 2 + (j - center[1]) ** 2
+            g = np.exp(-0.5 * d / (radius ** 2))
+            mask[i, j] = 1 - g if high else g
+    return torch.from_numpy(mask).float()               # (discards the zero imaginary part, as the reference's .float() does)
+
+
+def _mask(rows, cols, radius, high):
+    return gauss_mask_loop(rows, cols, radius, high) if MASK_STYLE == "loop" else gauss_mask(rows, cols, radius, high)
+
+
 def high_pass(timg, i=4):
     """utils.py:93-103: timg is (1,H,W); returns (H,W)."""
     f = torch.fft.fftshift(torch.fft.fft2(timg[0]))
-    f = f * gauss_mask(f.shape[0], f.shape[1], i, True).to(f.real.dtype)
+    f = f * _mask(f.shape[0], f.shape[1], i, True).to(f.real.dtype)
     return torch.abs(torch.fft.ifft2(torch.fft.ifftshift(f)))
 
 
 def low_pass(timg, i=10):
     """utils.py:105-117 (note the final ``* -1``)."""
     f = torch.fft.fftshift(torch.fft.fft2(timg[0]))
-    f = f * gauss_mask(f.shape[0], f.shape[1], i, False).to(f.real.dtype)
+    f = f * _mask(f.shape[0], f.shape[1], i, False).to(f.real.dtype)
     return torch.abs(torch.fft.ifft2(torch.fft.ifftshift(f))) * -1
 
 
@@ -702,3 +724,45 @@ def transform_B(img_u8, top, left, size_B=256):
     x = torch.as_tensor(img_u8).to(torch.float32).div(255.0)[None]
     x = (x - 0.5) / 0.5
     return x[:, top:top + size_B, left:left + size_B]
+
+
+# --------------------------------------------------------------------------
+# evaluation metrics (utils.py:209-212).  skimage is absent offline: these follow its PUBLISHED definitions (scikit-image
+# metrics module: peak_signal_noise_ratio, structural_similarity with its defaults, mean_squared_error,
+# normalized_mutual_information) and are pinned by closed-form cases only -- "parity unpinned" for this row.
+# --------------------------------------------------------------------------
+
+def skimage_mse(y, gt):
+    return float(np.mean((np.asarray(y, np.float64) - np.asarray(gt, np.float64)) ** 2))
+
+
+def skimage_psnr(y, gt, data_range=2.0):
+    err = skimage_mse(y, gt)
+    return float("inf") if err == 0 else 10.0 * math.log10(data_range ** 2 / err)
+
+
+def skimage_nmi(a, b, bins=100):
+    """(H(a) + H(b)) / H(a, b) on the joint ``bins`` x ``bins`` histogram (numpy.histogram2d over each image's [min, max])."""
+    h, _, _ = np.histogram2d(np.ravel(a), np.ravel(b), bins=bins)
+
+    def ent(p):
+        p = p[p > 0] / p.sum()
+        return float(-(p * np.log(p)).sum())
+    hj = ent(h.ravel())
+    return (ent(h.sum(1)) + ent(h.sum(0))) / hj if hj > 0 else 1.0
+
+
+def skimage_ssim(a, b, data_range=2.0, win=7):
+    """structural_similarity defaults for 2-D float images: 7x7 uniform window, K1 0.01, K2 0.03, sample covariance, mean over
+    the map cropped by (win-1)/2."""
+    from scipy.ndimage import uniform_filter
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    NP = win * win
+    cov_norm = NP / (NP - 1.0)
+    ux, uy = uniform_filter(a, win), uniform_filter(b, win)
+    uxx, uyy, uxy = uniform_filter(a * a, win), uniform_filter(b * b, win), uniform_filter(a * b, win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
+    p = (win - 1) // 2
+    return float(S[p:-p, p:-p].mean())

@@ -535,3 +535,91 @@ def test_input_pipeline_vs_oracle(fa, O):
     assert list(zip(t1, l1)) == exp
     with pytest.raises(ValueError):
         fa.crop_resize_normalize(img.cuda(), tops, lefts, 160, 320)
+
+
+GUARD_CASES = [
+    # N, C, H, W, M, k, stride, pad  -- Winograd-eligible shapes with every kind of tail, plus LDS-patch and flat-kernel shapes
+    (4, 20, 33, 47, 70, 3, 1, 1),      # Winograd: odd H/W (tail tiles), channel tail (20 = 16 + 4), M tail (70 = 64 + 6)
+    (8, 64, 32, 32, 64, 3, 1, 1),      # Winograd: exact tiles
+    (2, 24, 40, 72, 96, 3, 1, 1),      # Winograd / patch config C
+    (2, 64, 64, 96, 128, 3, 2, 1),     # patch kernel, stride 2
+    (2, 512, 4, 4, 512, 4, 1, 1),      # flat kernel with split-K
+]
+
+
+@pytest.mark.parametrize("case", GUARD_CASES)
+def test_conv_kernels_stay_inside_their_buffers(fa, case):
+    """Regression guard for the GPU memory-access fault recorded in round 1 (gpurun_out/wino_abl0.log: a hand-built, never
+    committed Winograd ablation variant faulted on its first launch; cause not recoverable -- DESIGN.md 4.1a).  What can be
+    pinned on the committed kernels is the class of error behind such a fault: every buffer the C ABI writes -- the packed
+    weight image (sized by faoctasr_conv_wpack_floats), y, dx and dw -- sits between two 4 KiB canary bands here, and the bands
+    must be intact after forward (pack + kernel), input gradient and weight gradient, for exact and ragged tile shapes."""
+    from faoctasr._lib import call, ptr, stream_ptr
+    N, C, H, W, M, k, s, p = case
+    lib = fa._lib.load()
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    G = 1024                                               # canary floats on each side
+    CAN = 1.2345e30
+
+    def banded(n):
+        t = torch.full((n + 2 * G,), CAN, device="cuda")
+        return t, t[G:G + n]
+
+    def intact(t, n, what):
+        assert bool((t[:G] == CAN).all()) and bool((t[G + n:] == CAN).all()), "%s: canary band overwritten" % what
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(M, C, k, k, generator=g) * 0.05).cuda()
+    dy = torch.randn(N, M, OH, OW, generator=g).cuda()
+    st = stream_ptr()
+    for kind, precision in ((0, 0), (0, 1), (1, 0)):       # forward (Winograd / direct), input gradient
+        nwp = lib.faoctasr_conv_wpack_floats(kind, C, M, k, k, s, p, precision)
+        wp_all, wp = banded(max(nwp, 1))
+        if kind == 0:
+            out_all, out = banded(N * M * OH * OW)
+            call("conv2d_fwd", ptr(x), ptr(w), None, ptr(out), N, C, H, W, M, k, k, s, p, 0, 0, 0.2, ptr(wp) if nwp > 0 else None,
+                 1 if nwp > 0 else 0, precision, st)
+            ref = F.conv2d(x.cpu(), w.cpu(), None, stride=s, padding=p)
+            torch.cuda.synchronize()
+            assert rel_l2(out.view(N, M, OH, OW), ref) < 2e-5
+            intact(out_all, N * M * OH * OW, "y")
+        else:
+            out_all, out = banded(N * C * H * W)
+            call("conv2d_dgrad", ptr(dy), ptr(w), ptr(out), N, C, H, W, M, k, k, s, p, ptr(wp) if nwp > 0 else None, 1 if nwp > 0 else 0,
+                 precision, st)
+            torch.cuda.synchronize()
+            intact(out_all, N * C * H * W, "dx")
+        intact(wp_all, max(nwp, 1), "wpack (kind %d, precision %d)" % (kind, precision))
+    dw_all, dw = banded(M * C * k * k)
+    dw.zero_()
+    call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, k, k, s, p, 0, 1, st)
+    torch.cuda.synchronize()
+    intact(dw_all, M * C * k * k, "dw")
+
+
+def test_eval_metrics_vs_oracle_and_closed_forms(fa, O):
+    """the four skimage metrics of utils.py:209-212 as device kernels (faoctasr_eval_metrics) against the oracle's
+    numpy restatements, on ragged and benchmark-size images, plus the closed-form cases the restatements themselves are pinned by."""
+    g = torch.Generator().manual_seed(9)
+    for N, H, W in ((3, 40, 56), (2, 256, 256), (1, 33, 71)):
+        a = torch.rand(N, 1, H, W, generator=g) * 2 - 1
+        b = (a + 0.15 * torch.randn(N, 1, H, W, generator=g)).clamp(-1, 1)
+        b[0] = torch.rand(1, H, W, generator=g) * 1.3 - 0.9                     # an unrelated image with another value range
+        m = fa.image_metrics(dev(a), dev(b)).cpu().numpy()
+        for n in range(N):
+            an, bn = a[n, 0].numpy(), b[n, 0].numpy()
+            assert m[n, 0] == pytest.approx(O.skimage_psnr(an, bn), rel=1e-6)
+            assert m[n, 1] == pytest.approx(O.skimage_ssim(an, bn), rel=2e-5, abs=1e-6)
+            assert m[n, 2] == pytest.approx(O.skimage_mse(an, bn), rel=1e-6)
+            assert m[n, 3] == pytest.approx(O.skimage_nmi(an, bn), rel=1e-9)      # same histogram bins as numpy, fp64 entropies
+    a = torch.rand(2, 1, 48, 48, generator=g) * 2 - 1
+    m = fa.image_metrics(dev(a), dev(a)).cpu().numpy()
+    assert np.isinf(m[:, 0]).all() and np.allclose(m[:, 1], 1.0, atol=1e-6) and (m[:, 2] == 0).all() and np.allclose(m[:, 3], 2.0, atol=1e-12)
+    c = torch.full((1, 1, 20, 20), 0.3)
+    d = torch.full((1, 1, 20, 20), -0.6)
+    m = fa.image_metrics(dev(c), dev(d)).cpu().numpy()[0]
+    assert m[1] == pytest.approx((2 * 0.3 * -0.6 + 4e-4) / (0.09 + 0.36 + 4e-4), rel=1e-5)
+    assert m[3] == pytest.approx(1.0, abs=1e-12)                                  # two constant images
+    m = fa.image_metrics(dev(a), dev(torch.full_like(a, 0.25))).cpu().numpy()
+    assert np.allclose(m[:, 3], 1.0, atol=1e-12)                                  # H(const) = 0

@@ -175,9 +175,19 @@ def test_inference_path_eval_mode(fa, O):
     out = fa.super_resolve(nets["A2B"], a.cuda())
     assert not nets["A2B"].training
     close(out, ref, rtol=1e-3, atol=2e-4)
+    # the same forward with gradients enabled takes the un-folded path (BatchNorm eval kernels): folding changes nothing beyond rounding
+    nets["A2B"].eval()
+    hf, lf = fa.frequency_split(a.cuda(), 10, 8)
+    unfolded = nets["A2B"](lf, hf)[2]
+    close(out, unfolded, rtol=1e-4, atol=2e-5)
     m = fa.evaluate_pairs(nets["A2B"], [(a[:1].cuda(), a[1:].cuda())])
     assert set(m) == {"psnr", "ssim", "mse", "nmi"} and m["mse"] > 0
-    assert m["psnr"] == pytest.approx(O.psnr(fa.super_resolve(nets["A2B"], a[:1].cuda()).cpu(), a[1:]), rel=1e-6)
+    y1 = fa.super_resolve(nets["A2B"], a[:1].cuda()).cpu().numpy()[0, 0]
+    g1 = a[1].numpy()[0]
+    assert m["psnr"] == pytest.approx(O.skimage_psnr(y1, g1), rel=1e-6)
+    assert m["mse"] == pytest.approx(O.skimage_mse(y1, g1), rel=1e-6)
+    assert m["ssim"] == pytest.approx(O.skimage_ssim(y1, g1), rel=1e-5, abs=1e-6)
+    assert m["nmi"] == pytest.approx(O.skimage_nmi(y1, g1), rel=1e-9)
     # LR schedule hook (train.py:105-110): linear decay to 0 after decay_epoch
     ts = fa.TrainStep(nets["A2B"], nets["B2A"], nets["D_A"], nets["D_B"])
     ts.lr_step(1.3e-4, fa.LambdaLR(50, 0, 10).step, 30)

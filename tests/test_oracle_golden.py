@@ -190,3 +190,37 @@ def test_train_step_vs_reference():
             assert gn[k] == pytest.approx(ref["grad_norm"][k], rel=2e-3 if step == 0 else 5e-2), (step, k)
     live = {k: sum(p.numel() for p in ps if p.grad is not None) for k, ps in S.params.items()}
     assert live == gold["live_params"]
+
+
+def test_reference_style_mask_loop_equals_vectorised_mask():
+    """The second cpu_baseline leg of bench.py builds the Gaussian masks the way the reference does on every call (Python double
+    loop into a complex array, utils.py:71-91); it must produce the very same fp32 masks as the vectorised form the oracle uses."""
+    import warnings
+    for rows, cols, r in ((32, 48, 5), (30, 34, 8), (17, 16, 14)):
+        for high in (False, True):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # ComplexWarning of the reference's own complex -> float cast
+                a = O.gauss_mask_loop(rows, cols, r, high)
+            assert torch.equal(a, O.gauss_mask(rows, cols, r, high))
+
+
+def test_skimage_metric_restatements_closed_forms():
+    """utils.py:209-212 scores with skimage, which is absent offline: the oracle restates the four metrics from their published
+    definitions; they are pinned by closed-form cases only (this row's oracle is 'parity unpinned')."""
+    rng = np.random.default_rng(3)
+    a = rng.uniform(-1, 1, (40, 56)).astype(np.float32)
+    b = np.clip(a + 0.1 * rng.standard_normal(a.shape), -1, 1).astype(np.float32)
+    assert O.skimage_ssim(a, a) == pytest.approx(1.0, abs=1e-12)
+    assert O.skimage_nmi(a, a) == pytest.approx(2.0, abs=1e-12)                      # H(a,a) = H(a)
+    assert O.skimage_nmi(a, np.full_like(a, 0.25)) == pytest.approx(1.0, abs=1e-12)  # H(const) = 0, H(a,const) = H(a)
+    assert O.skimage_mse(a, b) == pytest.approx(float(np.mean((a.astype(np.float64) - b) ** 2)))
+    assert O.skimage_psnr(a, b) == pytest.approx(10 * np.log10(4.0 / O.skimage_mse(a, b)))
+    assert O.skimage_psnr(a, a) == float("inf")
+    # two constant images: all (co)variances vanish, S = (2 c1 c2 + C1) / (c1^2 + c2^2 + C1) with C1 = (0.01 * 2)^2
+    c1, c2 = 0.3, -0.6
+    s = O.skimage_ssim(np.full((20, 20), c1), np.full((20, 20), c2))
+    assert s == pytest.approx((2 * c1 * c2 + 4e-4) / (c1 * c1 + c2 * c2 + 4e-4), rel=1e-9)
+    # independent images: NMI close to 1 (joint entropy ~ sum of the marginals), SSIM close to 0
+    c = rng.uniform(-1, 1, (128, 128))
+    d = rng.uniform(-1, 1, (128, 128))
+    assert 1.0 < O.skimage_nmi(c, d) < 1.2 and abs(O.skimage_ssim(c, d)) < 0.05
