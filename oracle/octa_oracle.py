@@ -743,7 +743,10 @@ def skimage_psnr(y, gt, data_range=2.0):
 
 def skimage_nmi(a, b, bins=100):
     """(H(a) + H(b)) / H(a, b) on the joint ``bins`` x ``bins`` histogram (numpy.histogram2d over each image's [min, max])."""
-    h, _, _ = np.histogram2d(np.ravel(a), np.ravel(b), bins=bins)
+    # float64 samples: the bin edges are then linspace(min, max, bins + 1) in float64, which is what the NumPy 1.x of the
+    # reference's era computed for float32 images too (NumPy 2 keeps float32 edges for float32 samples: a few pixels per
+    # image change bins, NMI moves by ~2e-6)
+    h, _, _ = np.histogram2d(np.ravel(a).astype(np.float64), np.ravel(b).astype(np.float64), bins=bins)
 
     def ent(p):
         p = p[p > 0] / p.sum()
