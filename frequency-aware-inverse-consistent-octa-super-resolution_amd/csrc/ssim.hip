@@ -6,6 +6,8 @@
 // Backward recomputes the moments on a halo, forms the five partial-derivative maps, and applies
 // the same separable filter to them (the window is symmetric, so the adjoint of the zero-padded
 // correlation is itself).
+#include <type_traits>
+
 #include "common.h"
 
 namespace faoctasr {
@@ -202,6 +204,318 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
     }
 }
 
+
+// ---- sliding-window forms (W even): no block-level barrier, no tile halo re-reads beyond 10 rows per row segment --------------
+// One WAVE owns a strip of 128 output columns (lane = 2 adjacent columns) and walks down a segment of rows.  Per input row:
+// the lane's (a, b) pairs go to a wave-private LDS row (plus 5 halo columns on each side, loaded by lanes 0..9), every lane reads
+// the 12 pairs its two columns need (6 ds_read_b128) and forms the five row-filtered moments; the column pass runs over an
+// 11-row register ring (row loop unrolled 11x, so ring slots are static registers).  LDS traffic 14 B in / 96 B out per lane and
+// row instead of ~135 B per pixel, one global read of each input, and the only synchronisation is the wave's own lgkmcnt.
+constexpr int SL_COLS = 128, SL_PAIRS = SL_COLS + 2 * R + 2;          // pairs per LDS row (index i <-> column x0 - 5 + i)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ss_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ss_static_for<I + 1, N>(f);
+    }
+}
+
+struct Mom { f2 m01, m23; float m4; };                                  // (mu_a, mu_b), (E a^2, E b^2), E ab
+
+// row-filtered moments of the lane's two columns from the 12 staged pairs
+__device__ __forceinline__ void row_moments(const f2 (&v)[12], const Taps& tp, Mom (&out)[2]) {
+    f2 sq[12];
+    float ab[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) { sq[q] = v[q] * v[q]; ab[q] = v[q][0] * v[q][1]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+        float s4 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float g = tp.g[k];
+            s01 += g * v[j + k];
+            s23 += g * sq[j + k];
+            s4 += g * ab[j + k];
+        }
+        out[j].m01 = s01; out[j].m23 = s23; out[j].m4 = s4;
+    }
+}
+
+// stage one input row of the strip in the wave's LDS row and fetch the lane's 12 pairs.  `cur` = this lane's two columns of
+// the row as loaded from global memory ((a0,a1),(b0,b1)), `halo` = the pair of the lane's halo column (lanes 0..9).
+__device__ __forceinline__ void exchange_row(f2* rowbuf, int lane, const f2& a2, const f2& b2, const f2& halo, f2 (&v)[12]) {
+    rowbuf[R + 2 * lane] = f2{a2[0], b2[0]};
+    rowbuf[R + 2 * lane + 1] = f2{a2[1], b2[1]};
+    if (lane < 2 * R) rowbuf[lane < R ? lane : SL_COLS + lane] = halo;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // other lanes' stores before this lane's loads: the wave runs
+    __builtin_amdgcn_wave_barrier();                                     // in lockstep and its LDS operations retire in order, so this
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");               // only pins the compiler's ordering (no instruction)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* src = reinterpret_cast<const f4v*>(rowbuf + 2 * lane);     // 16-byte aligned: pair index 2 * lane
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const f4v t = src[q];
+        v[2 * q] = f2{t[0], t[1]};
+        v[2 * q + 1] = f2{t[2], t[3]};
+    }
+}
+
+// work item -> (plane, strip, row segment)
+struct SlideItem { int plane, x0, r0, r1; bool valid; };
+__device__ __forceinline__ SlideItem slide_item(long item, int planes, int nstrips, int nseg, int seg_rows, int H) {
+    SlideItem it;
+    const int seg = (int)(item % nseg);
+    const long t = item / nseg;
+    const int strip = (int)(t % nstrips);
+    it.plane = (int)(t / nstrips);
+    it.valid = it.plane < planes;
+    it.x0 = strip * SL_COLS;
+    it.r0 = seg * seg_rows;
+    it.r1 = it.r0 + seg_rows < H ? it.r0 + seg_rows : H;
+    return it;
+}
+
+__global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ sums,
+                                                             int planes, int C, int H, int W, int nstrips, int nseg, int seg_rows, const Taps tp) {
+    __shared__ __attribute__((aligned(16))) f2 rows_lds[4][SL_PAIRS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const SlideItem it = slide_item((long)blockIdx.x * 4 + wave, planes, nstrips, nseg, seg_rows, H);
+    if (!it.valid || it.r0 >= it.r1) return;                             // whole waves only: no barrier anywhere in this kernel
+    f2* rowbuf = rows_lds[wave];
+    const float* ap = a + (long)it.plane * H * W;
+    const float* bp = b + (long)it.plane * H * W;
+    const int xc = it.x0 + 2 * lane;                                     // the lane's first column
+    const bool cin = xc < W;                                             // W even: both columns in or out
+    const int xh = lane < R ? it.x0 - R + lane : it.x0 + SL_COLS + (lane - R);      // halo column of lanes 0..9
+    const bool hin = lane < 2 * R && (unsigned)xh < (unsigned)W;
+    auto load_row = [&](int y, f2& a2, f2& b2, f2& halo) {
+        a2 = f2{0.f, 0.f}; b2 = f2{0.f, 0.f}; halo = f2{0.f, 0.f};
+        if ((unsigned)y < (unsigned)H) {                                 // uniform; rows outside the image are zero padding
+            if (cin) {
+                a2 = *reinterpret_cast<const f2*>(ap + (long)y * W + xc);
+                b2 = *reinterpret_cast<const f2*>(bp + (long)y * W + xc);
+            }
+            if (hin) halo = f2{ap[(long)y * W + xh], bp[(long)y * W + xh]};
+        }
+    };
+    Mom ring[11][2];
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { ring[s][j].m01 = f2{0.f, 0.f}; ring[s][j].m23 = f2{0.f, 0.f}; ring[s][j].m4 = 0.f; }
+    float local = 0.f;
+    const int y_first = it.r0 - R, y_last = it.r1 - 1 + R;              // input rows that feed the segment's outputs
+    f2 na2, nb2, nh;                                                     // the next row, loaded one iteration ahead
+    load_row(y_first, na2, nb2, nh);
+    for (int ybase = y_first; ybase <= y_last; ybase += 11) {
+        ss_static_for<0, 11>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int yin = ybase + j;
+            if (yin <= y_last) {                                         // uniform
+                const f2 a2 = na2, b2 = nb2, hh = nh;
+                if (yin + 1 <= y_last) load_row(yin + 1, na2, nb2, nh);
+                f2 v[12];
+                exchange_row(rowbuf, lane, a2, b2, hh, v);
+                row_moments(v, tp, ring[j]);
+                const int yo = yin - R;
+                if (yo >= it.r0) {                                       // rows yo-5 .. yo+5 sit in slots j+1 .. j+11 (mod 11)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        f2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
+                        float m4 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 11; ++k) {
+                            const Mom& h = ring[(j + 1 + k) % 11][c];
+                            const float g = tp.g[k];
+                            m01 += g * h.m01; m23 += g * h.m23; m4 += g * h.m4;
+                        }
+                        if (xc + c < W) local += ssim_point(m01[0], m01[1], m23[0], m23[1], m4);
+                    }
+                }
+            }
+        });
+    }
+    local = wave_sum(local);
+    if (lane == 0) atomicAdd(sums + it.plane / C, local);
+}
+
+
+// Backward, sliding form.  Two separable filters in sequence per wave: (1) moments -> the five partial-derivative maps
+// f = d ssim / d (mu_a, mu_b, E a^2, E b^2, E ab) at the rows that have left the first ring; (2) the same window applied to f
+// (the window is symmetric, so the adjoint of the zero-padded correlation is itself) through a second exchange + ring; then
+// da = g (F0 + 2 a F2 + b F4), db = g (F1 + 2 b F3 + a F4).  A wave computes f on its 128 lane columns and gradients on the
+// inner 116 (strips overlap by 12 columns, row segments by 20 rows); one wave per 64-thread block (two 11-row rings = 220 VGPRs).
+constexpr int SB_OUT = 116, SB_LEFT = 6;                                 // output columns x0+6 .. x0+121 of the 128 lane columns
+struct F5 { f2 f01, f23; float f4; };
+
+__device__ __forceinline__ F5 ssim_partials(const Mom& m) {
+    const float m1 = m.m01[0], m2 = m.m01[1];
+    const float s11 = m.m23[0] - m1 * m1, s22 = m.m23[1] - m2 * m2, s12 = m.m4 - m1 * m2;
+    const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
+    const float inv = 1.f / (B1 * B2);
+    const float S = A1 * A2 * inv;
+    F5 f;
+    f.f01 = f2{(2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 / B1 - 2.f * m1 / B2), (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 / B1 - 2.f * m2 / B2)};
+    f.f23 = f2{-S / B2, -S / B2};
+    f.f4 = 2.f * A1 * inv;
+    return f;
+}
+
+__global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
+                                                            int gN, float gscale, float* __restrict__ da, float* __restrict__ db, int planes, int C,
+                                                            int H, int W, int nstrips, int nseg, int seg_rows, const Taps tp) {
+    __shared__ __attribute__((aligned(16))) f2 rowbuf[SL_PAIRS];
+    __shared__ __attribute__((aligned(16))) f2 fbuf[(SL_COLS + 12) * 3];    // per column (f0,f1),(f2,f3),(f4,-); index i <-> column x0 - 6 + i
+    const int lane = threadIdx.x;
+    SlideItem it;
+    {
+        const long item = blockIdx.x;
+        const int seg = (int)(item % nseg);
+        const long t = item / nseg;
+        const int strip = (int)(t % nstrips);
+        it.plane = (int)(t / nstrips);
+        it.valid = it.plane < planes;
+        it.x0 = strip * SB_OUT - SB_LEFT;
+        it.r0 = seg * seg_rows;
+        it.r1 = it.r0 + seg_rows < H ? it.r0 + seg_rows : H;
+    }
+    if (!it.valid || it.r0 >= it.r1) return;
+    const float* ap = a + (long)it.plane * H * W;
+    const float* bp = b + (long)it.plane * H * W;
+    const int xc = it.x0 + 2 * lane;                                     // even (x0 even): the lane's two columns are both in or both out
+    const bool cin = (unsigned)xc < (unsigned)W;
+    const int xh = lane < R ? it.x0 - R + lane : it.x0 + SL_COLS + (lane - R);
+    const bool hin = lane < 2 * R && (unsigned)xh < (unsigned)W;
+    const bool cout = cin && 2 * lane >= SB_LEFT && 2 * lane < SB_LEFT + SB_OUT;      // this lane writes gradients
+    auto load_row = [&](int y, f2& a2, f2& b2, f2& halo) {
+        a2 = f2{0.f, 0.f}; b2 = f2{0.f, 0.f}; halo = f2{0.f, 0.f};
+        if ((unsigned)y < (unsigned)H) {
+            if (cin) {
+                a2 = *reinterpret_cast<const f2*>(ap + (long)y * W + xc);
+                b2 = *reinterpret_cast<const f2*>(bp + (long)y * W + xc);
+            }
+            if (hin) halo = f2{ap[(long)y * W + xh], bp[(long)y * W + xh]};
+        }
+    };
+    const float gv = gout[gN > 1 ? it.plane / C : 0] * gscale;
+    Mom ring1[11][2];
+    F5 ring2[11][2];
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ring1[s][j].m01 = f2{0.f, 0.f}; ring1[s][j].m23 = f2{0.f, 0.f}; ring1[s][j].m4 = 0.f;
+            ring2[s][j].f01 = f2{0.f, 0.f}; ring2[s][j].f23 = f2{0.f, 0.f}; ring2[s][j].f4 = 0.f;
+        }
+    // input row yin enters ring 1; the map row yo1 = yin - 5 leaves it as f and enters ring 2 (row-filtered); the gradient row
+    // yo2 = yin - 10 leaves ring 2.  Rows outside the image are zero in both stages.
+    const int y_first = it.r0 - 2 * R, y_last = it.r1 - 1 + 2 * R;
+    f2 na2, nb2, nh;
+    load_row(y_first, na2, nb2, nh);
+    for (int ybase = y_first; ybase <= y_last; ybase += 11) {
+        ss_static_for<0, 11>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int yin = ybase + j;
+            if (yin <= y_last) {
+                const f2 a2 = na2, b2 = nb2, hh = nh;
+                if (yin + 1 <= y_last) load_row(yin + 1, na2, nb2, nh);
+                f2 v[12];
+                exchange_row(rowbuf, lane, a2, b2, hh, v);
+                row_moments(v, tp, ring1[j]);
+                // stage 1 column pass -> partials of map row yo1 on the lane's two columns
+                const int yo1 = yin - R;
+                F5 f[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    Mom m;
+                    m.m01 = f2{0.f, 0.f}; m.m23 = f2{0.f, 0.f}; m.m4 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) {
+                        const Mom& h = ring1[(j + 1 + k) % 11][c];
+                        const float g = tp.g[k];
+                        m.m01 += g * h.m01; m.m23 += g * h.m23; m.m4 += g * h.m4;
+                    }
+                    f[c] = ssim_partials(m);
+                    if (!cin || (unsigned)yo1 >= (unsigned)H) { f[c].f01 = f2{0.f, 0.f}; f[c].f23 = f2{0.f, 0.f}; f[c].f4 = 0.f; }
+                }
+                // exchange f across the lanes: column index i = 6 + 2 lane + c
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f2* dst = fbuf + (SB_LEFT + 2 * lane + c) * 3;
+                    dst[0] = f[c].f01; dst[1] = f[c].f23; dst[2] = f2{f[c].f4, 0.f};
+                }
+                if (lane < 6) {                                         // columns x0-6 .. x0-1 and x0+128 .. x0+133 never hold map values
+                    f2* z0 = fbuf + lane * 3;
+                    f2* z1 = fbuf + (SB_LEFT + SL_COLS + lane) * 3;
+                    z0[0] = z0[1] = z0[2] = f2{0.f, 0.f};
+                    z1[0] = z1[1] = z1[2] = f2{0.f, 0.f};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the lane's output columns need f columns (2 lane + c) - 5 .. + 5 -> indices 2 lane + 1 .. 2 lane + 12
+                F5 w[12];
+                {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v* src = reinterpret_cast<const f4v*>(fbuf + (2 * lane) * 3);     // 48 * lane bytes: 16-byte aligned
+                    float t[13 * 6];
+#pragma unroll
+                    for (int q = 0; q < 20; ++q) {                       // columns 2 lane .. 2 lane + 12 (13 columns x 6 floats = 78 floats)
+                        const f4v r = src[q];
+                        if (4 * q + 0 < 78) t[4 * q + 0] = r[0];
+                        if (4 * q + 1 < 78) t[4 * q + 1] = r[1];
+                        if (4 * q + 2 < 78) t[4 * q + 2] = r[2];
+                        if (4 * q + 3 < 78) t[4 * q + 3] = r[3];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        w[q].f01 = f2{t[6 * (q + 1)], t[6 * (q + 1) + 1]};
+                        w[q].f23 = f2{t[6 * (q + 1) + 2], t[6 * (q + 1) + 3]};
+                        w[q].f4 = t[6 * (q + 1) + 4];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+                    float s4 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) {
+                        const float g = tp.g[k];
+                        s01 += g * w[c + k].f01; s23 += g * w[c + k].f23; s4 += g * w[c + k].f4;
+                    }
+                    ring2[j][c].f01 = s01; ring2[j][c].f23 = s23; ring2[j][c].f4 = s4;
+                }
+                // stage 2 column pass -> gradient row yo2
+                const int yo2 = yin - 2 * R;
+                if (yo2 >= it.r0 && cout) {                              // (yo2 < r1 by construction of y_last)
+                    const f2 av = *reinterpret_cast<const f2*>(ap + (long)yo2 * W + xc);
+                    const f2 bv = *reinterpret_cast<const f2*>(bp + (long)yo2 * W + xc);
+                    f2 oa, ob;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+                        float s4 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 11; ++k) {
+                            const F5& h = ring2[(j + 1 + k) % 11][c];
+                            const float g = tp.g[k];
+                            s01 += g * h.f01; s23 += g * h.f23; s4 += g * h.f4;
+                        }
+                        oa[c] = gv * (s01[0] + 2.f * av[c] * s23[0] + bv[c] * s4);
+                        ob[c] = gv * (s01[1] + 2.f * bv[c] * s23[1] + av[c] * s4);
+                    }
+                    const long off = (long)it.plane * H * W + (long)yo2 * W + xc;
+                    if (da) *reinterpret_cast<f2*>(da + off) = oa;
+                    if (db) *reinterpret_cast<f2*>(db + off) = ob;
+                }
+            }
+        });
+    }
+}
+
 static Taps make_taps() {
     // ssim.py:7-9: gauss = Tensor([exp(-(x - 5)^2 / (2 * 1.5^2))]) (fp32) / gauss.sum()
     Taps t;
@@ -226,6 +540,17 @@ int faoctasr_ssim_fwd(const float* a, const float* b, float* sums, int N, int C,
     if ((long)N * C > 65535) return fail(FAOCTASR_EUNSUPPORTED, "ssim_fwd: more than 65535 planes");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sums, 0, sizeof(float) * N, st) != hipSuccess) return fail(FAOCTASR_EHIP, "ssim_fwd: memset failed");
+    if ((W & 1) == 0) {
+        // sliding-window form: one wave per (plane, 128-column strip, row segment); segments sized so that ~2048+ waves exist
+        const int planes = N * C, nstrips = (W + SL_COLS - 1) / SL_COLS;
+        int seg_rows = H;
+        while ((long)planes * nstrips * ((H + seg_rows - 1) / seg_rows) < 2048 && seg_rows > 32) seg_rows = (seg_rows + 1) / 2;
+        const int nseg = (H + seg_rows - 1) / seg_rows;
+        const long items = (long)planes * nstrips * nseg;
+        hipLaunchKernelGGL(ssim_fwd_slide_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a, b, sums, planes, C, H, W, nstrips, nseg,
+                           seg_rows, make_taps());
+        return check_launch("ssim_fwd");
+    }
     dim3 grid((W + SF_TX - 1) / SF_TX, (H + SF_TY - 1) / SF_TY, N * C);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(512), 0, st, a, b, sums, C, H, W, make_taps());
     return check_launch("ssim_fwd");
@@ -237,6 +562,16 @@ int faoctasr_ssim_bwd(const float* a, const float* b, const float* g, int gN, fl
     if (gN != 1 && gN != N) return fail(FAOCTASR_EINVAL, "ssim_bwd: gN must be 1 or N");
     if ((long)N * C > 65535) return fail(FAOCTASR_EUNSUPPORTED, "ssim_bwd: more than 65535 planes");
     if (!da && !db) return FAOCTASR_OK;
+    if ((W & 1) == 0) {
+        const int planes = N * C, nstrips = (W + SB_OUT - 1) / SB_OUT;
+        int seg_rows = H;
+        while ((long)planes * nstrips * ((H + seg_rows - 1) / seg_rows) < 2048 && seg_rows > 64) seg_rows = (seg_rows + 1) / 2;
+        const int nseg = (H + seg_rows - 1) / seg_rows;
+        const long items = (long)planes * nstrips * nseg;
+        hipLaunchKernelGGL(ssim_bwd_slide_kernel, dim3((unsigned)items), dim3(64), 0, (hipStream_t)stream, a, b, g, gN, gscale, da, db, planes, C, H, W,
+                           nstrips, nseg, seg_rows, make_taps());
+        return check_launch("ssim_bwd");
+    }
     dim3 grid((W + 31) / 32, (H + 15) / 16, N * C);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, b, g, gN, gscale, da, db, C, H, W, make_taps());
     return check_launch("ssim_bwd");

@@ -375,6 +375,20 @@ def test_ssim_vs_golden_and_oracle(fa, O):
     (vd * dev(wt)).sum().backward()
     assert rel_l2(ad.grad, ar.grad) < 1e-4
     assert float(fa.ssim.ssim(dev(ab), dev(ab))) == pytest.approx(1.0, abs=1e-6)     # identity property
+    # sliding-window kernels: several 128 / 116-column strips with a partial last strip, several row segments, non-square;
+    # and an odd width, which takes the tile kernels
+    for shape in ((1, 2, 70, 300), (2, 1, 45, 33), (3, 1, 200, 118)):
+        x1 = torch.rand(shape, generator=gen) * 2 - 1
+        x2 = (x1 + 0.25 * torch.randn(shape, generator=gen)).clamp(-1, 1)
+        r1, r2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        vr = O.ssim(r1, r2, size_average=False)
+        wt = torch.arange(1, shape[0] + 1, dtype=torch.float32)
+        (vr * wt).sum().backward()
+        d1, d2 = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+        vd = fa.ssim.ssim(d1, d2, size_average=False)
+        close(vd, vr, rtol=1e-5, atol=1e-6)
+        (vd * dev(wt)).sum().backward()
+        assert rel_l2(d1.grad, r1.grad) < 1e-4 and rel_l2(d2.grad, r2.grad) < 1e-4, shape
 
 
 def test_losses_head_adamw(fa, O):
