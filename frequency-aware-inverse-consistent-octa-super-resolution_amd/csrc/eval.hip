@@ -6,8 +6,7 @@
 //   skimage.metrics.normalized_mutual_information(y, gt)             (H(y) + H(gt)) / H(y, gt) on the joint 100 x 100 histogram
 //                                                                    over [min, max] of each image (numpy.histogram2d semantics)
 // The reference copies every output to the host and scores it with skimage; here the super-resolved image never leaves the GPU:
-// four small kernels per batch of image pairs, results as doubles [N][4] = {psnr, ssim, mse, nmi}.  Accumulation is fp64 (the
-// per-pixel SSIM terms are fp32); histogram bin edges follow numpy.linspace in fp64 so that bin membership is numpy's.
+// four small kernels per batch of image pairs, results as doubles [N][4] = {psnr, ssim, mse, nmi}.  All arithmetic is fp64; histogram bin edges follow numpy.linspace in fp64 so that bin membership is numpy's.
 // BatchNorm folding for the inference forward (conv weights scaled by gamma / sqrt(var + eps)) lives here too.
 #include "common.h"
 
@@ -73,27 +72,29 @@ __global__ __launch_bounds__(256) void eval_sqerr_ssim_kernel(const float* __res
         gs[i] = in ? gp[(long)yy * W + xx] : 0.f;
     }
     __syncthreads();
-    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
-    const float inv = 1.0f / (float)(EV_WIN * EV_WIN), cov_norm = (float)(EV_WIN * EV_WIN) / (float)(EV_WIN * EV_WIN - 1);
+    // fp64 throughout (the kernel is nowhere near a bottleneck): in fp32 the variances of flat regions are rounding noise that is
+    // not small against C2 = (0.03 R)^2 (two constant images: 2e-4 relative on the result)
+    const double C1 = (0.01 * (double)data_range) * (0.01 * (double)data_range), C2 = (0.03 * (double)data_range) * (0.03 * (double)data_range);
+    const double inv = 1.0 / (double)(EV_WIN * EV_WIN), cov_norm = (double)(EV_WIN * EV_WIN) / (double)(EV_WIN * EV_WIN - 1);
     double se = 0.0, ss = 0.0;
     for (int i = threadIdx.x; i < T * T; i += 256) {
         const int r = i / T, c = i - r * T;
         const int yy = y0 + r, xx = x0 + c;
         if (yy >= H || xx >= W) continue;
-        const float d = ys[(r + EV_PAD) * PW + c + EV_PAD] - gs[(r + EV_PAD) * PW + c + EV_PAD];
-        se += (double)d * (double)d;
+        const double d = (double)ys[(r + EV_PAD) * PW + c + EV_PAD] - (double)gs[(r + EV_PAD) * PW + c + EV_PAD];
+        se += d * d;
         if (yy < EV_PAD || yy >= H - EV_PAD || xx < EV_PAD || xx >= W - EV_PAD) continue;      // skimage crops the map by (win-1)/2
-        float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+        double sa = 0.0, sb = 0.0, saa = 0.0, sbb = 0.0, sab = 0.0;
 #pragma unroll
         for (int u = 0; u < EV_WIN; ++u)
 #pragma unroll
             for (int v = 0; v < EV_WIN; ++v) {
-                const float a = ys[(r + u) * PW + c + v], b = gs[(r + u) * PW + c + v];
+                const double a = (double)ys[(r + u) * PW + c + v], b = (double)gs[(r + u) * PW + c + v];
                 sa += a; sb += b; saa += a * a; sbb += b * b; sab += a * b;
             }
-        const float ux = sa * inv, uy = sb * inv;
-        const float vx = cov_norm * (saa * inv - ux * ux), vy = cov_norm * (sbb * inv - uy * uy), vxy = cov_norm * (sab * inv - ux * uy);
-        ss += (double)(((2.f * ux * uy + C1) * (2.f * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2)));
+        const double ux = sa * inv, uy = sb * inv;
+        const double vx = cov_norm * (saa * inv - ux * ux), vy = cov_norm * (sbb * inv - uy * uy), vxy = cov_norm * (sab * inv - ux * uy);
+        ss += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
     }
     se = block_sum_256d(se, red);
     ss = block_sum_256d(ss, red);

@@ -301,34 +301,39 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
             if (hin) halo = f2{ap[(long)y * W + xh], bp[(long)y * W + xh]};
         }
     };
-    Mom ring[11][2];
+    // ring of 12 slots (11 live rows + the one being written) so that the 12x unrolled row loop also keeps a static 3-deep
+    // register prefetch of input rows: at ~760 cycles of arithmetic per row and two waves per SIMD, one row of lookahead left
+    // the HBM latency exposed (226 us per 512 planes; 3 rows: see DESIGN.md 4.3)
+    constexpr int RING = 12, PF = 3;
+    Mom ring[RING][2];
 #pragma unroll
-    for (int s = 0; s < 11; ++s)
+    for (int s = 0; s < RING; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j) { ring[s][j].m01 = f2{0.f, 0.f}; ring[s][j].m23 = f2{0.f, 0.f}; ring[s][j].m4 = 0.f; }
     float local = 0.f;
     const int y_first = it.r0 - R, y_last = it.r1 - 1 + R;              // input rows that feed the segment's outputs
-    f2 na2, nb2, nh;                                                     // the next row, loaded one iteration ahead
-    load_row(y_first, na2, nb2, nh);
-    for (int ybase = y_first; ybase <= y_last; ybase += 11) {
-        ss_static_for<0, 11>([&](auto jc) {
+    f2 na2[PF], nb2[PF], nh[PF];                                         // rows yin .. yin + PF - 1, slot = row index mod PF
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_row(y_first + p <= y_last ? y_first + p : -1, na2[p], nb2[p], nh[p]);
+    for (int ybase = y_first; ybase <= y_last; ybase += RING) {
+        ss_static_for<0, RING>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int yin = ybase + j;
             if (yin <= y_last) {                                         // uniform
-                const f2 a2 = na2, b2 = nb2, hh = nh;
-                if (yin + 1 <= y_last) load_row(yin + 1, na2, nb2, nh);
+                const f2 a2 = na2[j % PF], b2 = nb2[j % PF], hh = nh[j % PF];
+                load_row(yin + PF <= y_last ? yin + PF : -1, na2[j % PF], nb2[j % PF], nh[j % PF]);
                 f2 v[12];
                 exchange_row(rowbuf, lane, a2, b2, hh, v);
                 row_moments(v, tp, ring[j]);
                 const int yo = yin - R;
-                if (yo >= it.r0) {                                       // rows yo-5 .. yo+5 sit in slots j+1 .. j+11 (mod 11)
+                if (yo >= it.r0) {                                       // rows yo-5 .. yo+5 = yin-10 .. yin sit in slots j+2 .. j+12 (mod 12)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         f2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
                         float m4 = 0.f;
 #pragma unroll
                         for (int k = 0; k < 11; ++k) {
-                            const Mom& h = ring[(j + 1 + k) % 11][c];
+                            const Mom& h = ring[(j + 2 + k) % RING][c];
                             const float g = tp.g[k];
                             m01 += g * h.m01; m23 += g * h.m23; m4 += g * h.m4;
                         }
@@ -355,11 +360,12 @@ __device__ __forceinline__ F5 ssim_partials(const Mom& m) {
     const float m1 = m.m01[0], m2 = m.m01[1];
     const float s11 = m.m23[0] - m1 * m1, s22 = m.m23[1] - m2 * m2, s12 = m.m4 - m1 * m2;
     const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
-    const float inv = 1.f / (B1 * B2);
+    const float rB1 = 1.f / B1, rB2 = 1.f / B2;                          // two divisions instead of seven
+    const float inv = rB1 * rB2;
     const float S = A1 * A2 * inv;
     F5 f;
-    f.f01 = f2{(2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 / B1 - 2.f * m1 / B2), (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 / B1 - 2.f * m2 / B2)};
-    f.f23 = f2{-S / B2, -S / B2};
+    f.f01 = f2{(2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 * rB1 - 2.f * m1 * rB2), (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 * rB1 - 2.f * m2 * rB2)};
+    f.f23 = f2{-S * rB2, -S * rB2};
     f.f4 = 2.f * A1 * inv;
     return f;
 }
@@ -422,6 +428,13 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
             if (yin <= y_last) {
                 const f2 a2 = na2, b2 = nb2, hh = nh;
                 if (yin + 1 <= y_last) load_row(yin + 1, na2, nb2, nh);
+                // the inputs of the gradient row this iteration will finish (L2-resident: read 10 rows ago), issued before the arithmetic
+                const int yo2 = yin - 2 * R;
+                f2 av = {0.f, 0.f}, bv = {0.f, 0.f};
+                if (yo2 >= it.r0 && cout) {
+                    av = *reinterpret_cast<const f2*>(ap + (long)yo2 * W + xc);
+                    bv = *reinterpret_cast<const f2*>(bp + (long)yo2 * W + xc);
+                }
                 f2 v[12];
                 exchange_row(rowbuf, lane, a2, b2, hh, v);
                 row_moments(v, tp, ring1[j]);
@@ -489,10 +502,7 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
                     ring2[j][c].f01 = s01; ring2[j][c].f23 = s23; ring2[j][c].f4 = s4;
                 }
                 // stage 2 column pass -> gradient row yo2
-                const int yo2 = yin - 2 * R;
                 if (yo2 >= it.r0 && cout) {                              // (yo2 < r1 by construction of y_last)
-                    const f2 av = *reinterpret_cast<const f2*>(ap + (long)yo2 * W + xc);
-                    const f2 bv = *reinterpret_cast<const f2*>(bp + (long)yo2 * W + xc);
                     f2 oa, ob;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
