@@ -12,6 +12,9 @@ ROOT = os.path.dirname(HERE)
 SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "wgrad_patch.hip", "wgrad_s1.hip", "conv_m1.hip", "pointwise.hip", "norm.hip", "sgemm.hip",
            "ssim.hip", "eval.hip", "comm.hip"]
 HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(ROOT, "include", "faoctasr.h")]
+#: per-source extra flags.  ssim.hip: the SLP vectoriser re-packs the scalar 11-tap filters into v_pk_fma_f32, which has the FLOP
+#: rate of two v_fma_f32 here and costs ~85 v_mov per filtered row to keep operands in aligned register pairs
+FILE_FLAGS = {"ssim.hip": ["-fno-slp-vectorize"]}
 LIB = os.path.join(HERE, "libfaoctasr.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 
@@ -43,7 +46,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ_DIR, s + (("." + tag) if tag else "") + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            jobs.append((s, [hipcc] + _flags() + ["-c", src, "-o", obj]))
+            jobs.append((s, [hipcc] + _flags() + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]))
 
     def run(job):
         name, cmd = job

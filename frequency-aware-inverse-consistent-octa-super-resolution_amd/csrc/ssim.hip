@@ -221,27 +221,31 @@ __device__ __forceinline__ void ss_static_for(F&& f) {
     }
 }
 
-struct Mom { f2 m01, m23; float m4; };                                  // (mu_a, mu_b), (E a^2, E b^2), E ab
+// planar scalars: v_pk_fma_f32 has the FLOP rate of two v_fma_f32 on this chip, and the packed form cost ~85 v_mov per row to
+// keep its operands in aligned register pairs (ISA count of the first version)
+struct Mom { float ma, mb, maa, mbb, mab; };                             // mu_a, mu_b, E a^2, E b^2, E ab
 
 // row-filtered moments of the lane's two columns from the 12 staged pairs
 __device__ __forceinline__ void row_moments(const f2 (&v)[12], const Taps& tp, Mom (&out)[2]) {
-    f2 sq[12];
-    float ab[12];
+    float aa[12], bb[12], ab[12];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) { sq[q] = v[q] * v[q]; ab[q] = v[q][0] * v[q][1]; }
+    for (int q = 0; q < 12; ++q) { aa[q] = v[q][0] * v[q][0]; bb[q] = v[q][1] * v[q][1]; ab[q] = v[q][0] * v[q][1]; }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-        float s4 = 0.f;
+        Mom s = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             const float g = tp.g[k];
-            s01 += g * v[j + k];
-            s23 += g * sq[j + k];
-            s4 += g * ab[j + k];
+            s.ma += g * v[j + k][0]; s.mb += g * v[j + k][1];
+            s.maa += g * aa[j + k]; s.mbb += g * bb[j + k]; s.mab += g * ab[j + k];
         }
-        out[j].m01 = s01; out[j].m23 = s23; out[j].m4 = s4;
+        out[j] = s;
     }
+}
+
+__device__ __forceinline__ Mom mom_zero() { return Mom{0.f, 0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void mom_axpy(Mom& acc, float g, const Mom& h) {
+    acc.ma += g * h.ma; acc.mb += g * h.mb; acc.maa += g * h.maa; acc.mbb += g * h.mbb; acc.mab += g * h.mab;
 }
 
 // stage one input row of the strip in the wave's LDS row and fetch the lane's 12 pairs.  `cur` = this lane's two columns of
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < RING; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { ring[s][j].m01 = f2{0.f, 0.f}; ring[s][j].m23 = f2{0.f, 0.f}; ring[s][j].m4 = 0.f; }
+        for (int j = 0; j < 2; ++j) ring[s][j] = mom_zero();
     float local = 0.f;
     const int y_first = it.r0 - R, y_last = it.r1 - 1 + R;              // input rows that feed the segment's outputs
     f2 na2[PF], nb2[PF], nh[PF];                                         // rows yin .. yin + PF - 1, slot = row index mod PF
@@ -329,15 +333,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
                 if (yo >= it.r0) {                                       // rows yo-5 .. yo+5 = yin-10 .. yin sit in slots j+2 .. j+12 (mod 12)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        f2 m01 = {0.f, 0.f}, m23 = {0.f, 0.f};
-                        float m4 = 0.f;
+                        Mom m = mom_zero();
 #pragma unroll
-                        for (int k = 0; k < 11; ++k) {
-                            const Mom& h = ring[(j + 2 + k) % RING][c];
-                            const float g = tp.g[k];
-                            m01 += g * h.m01; m23 += g * h.m23; m4 += g * h.m4;
-                        }
-                        if (xc + c < W) local += ssim_point(m01[0], m01[1], m23[0], m23[1], m4);
+                        for (int k = 0; k < 11; ++k) mom_axpy(m, tp.g[k], ring[(j + 2 + k) % RING][c]);
+                        if (xc + c < W) local += ssim_point(m.ma, m.mb, m.maa, m.mbb, m.mab);
                     }
                 }
             }
@@ -354,20 +353,26 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
 // da = g (F0 + 2 a F2 + b F4), db = g (F1 + 2 b F3 + a F4).  A wave computes f on its 128 lane columns and gradients on the
 // inner 116 (strips overlap by 12 columns, row segments by 20 rows); one wave per 64-thread block (two 11-row rings = 220 VGPRs).
 constexpr int SB_OUT = 116, SB_LEFT = 6;                                 // output columns x0+6 .. x0+121 of the 128 lane columns
-struct F5 { f2 f01, f23; float f4; };
+struct F5 { float f0, f1, f2_, f3, f4; };
 
 __device__ __forceinline__ F5 ssim_partials(const Mom& m) {
-    const float m1 = m.m01[0], m2 = m.m01[1];
-    const float s11 = m.m23[0] - m1 * m1, s22 = m.m23[1] - m2 * m2, s12 = m.m4 - m1 * m2;
+    const float m1 = m.ma, m2 = m.mb;
+    const float s11 = m.maa - m1 * m1, s22 = m.mbb - m2 * m2, s12 = m.mab - m1 * m2;
     const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
     const float rB1 = 1.f / B1, rB2 = 1.f / B2;                          // two divisions instead of seven
     const float inv = rB1 * rB2;
     const float S = A1 * A2 * inv;
     F5 f;
-    f.f01 = f2{(2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 * rB1 - 2.f * m1 * rB2), (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 * rB1 - 2.f * m2 * rB2)};
-    f.f23 = f2{-S * rB2, -S * rB2};
+    f.f0 = (2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 * rB1 - 2.f * m1 * rB2);
+    f.f1 = (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 * rB1 - 2.f * m2 * rB2);
+    f.f2_ = -S * rB2;
+    f.f3 = f.f2_;
     f.f4 = 2.f * A1 * inv;
     return f;
+}
+__device__ __forceinline__ F5 f5_zero() { return F5{0.f, 0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void f5_axpy(F5& acc, float g, const F5& h) {
+    acc.f0 += g * h.f0; acc.f1 += g * h.f1; acc.f2_ += g * h.f2_; acc.f3 += g * h.f3; acc.f4 += g * h.f4;
 }
 
 __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
@@ -412,10 +417,7 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
 #pragma unroll
     for (int s = 0; s < 11; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            ring1[s][j].m01 = f2{0.f, 0.f}; ring1[s][j].m23 = f2{0.f, 0.f}; ring1[s][j].m4 = 0.f;
-            ring2[s][j].f01 = f2{0.f, 0.f}; ring2[s][j].f23 = f2{0.f, 0.f}; ring2[s][j].f4 = 0.f;
-        }
+        for (int j = 0; j < 2; ++j) { ring1[s][j] = mom_zero(); ring2[s][j] = f5_zero(); }
     // input row yin enters ring 1; the map row yo1 = yin - 5 leaves it as f and enters ring 2 (row-filtered); the gradient row
     // yo2 = yin - 10 leaves ring 2.  Rows outside the image are zero in both stages.
     const int y_first = it.r0 - 2 * R, y_last = it.r1 - 1 + 2 * R;
@@ -443,22 +445,17 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
                 F5 f[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    Mom m;
-                    m.m01 = f2{0.f, 0.f}; m.m23 = f2{0.f, 0.f}; m.m4 = 0.f;
+                    Mom m = mom_zero();
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) {
-                        const Mom& h = ring1[(j + 1 + k) % 11][c];
-                        const float g = tp.g[k];
-                        m.m01 += g * h.m01; m.m23 += g * h.m23; m.m4 += g * h.m4;
-                    }
+                    for (int k = 0; k < 11; ++k) mom_axpy(m, tp.g[k], ring1[(j + 1 + k) % 11][c]);
                     f[c] = ssim_partials(m);
-                    if (!cin || (unsigned)yo1 >= (unsigned)H) { f[c].f01 = f2{0.f, 0.f}; f[c].f23 = f2{0.f, 0.f}; f[c].f4 = 0.f; }
+                    if (!cin || (unsigned)yo1 >= (unsigned)H) f[c] = f5_zero();
                 }
                 // exchange f across the lanes: column index i = 6 + 2 lane + c
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     f2* dst = fbuf + (SB_LEFT + 2 * lane + c) * 3;
-                    dst[0] = f[c].f01; dst[1] = f[c].f23; dst[2] = f2{f[c].f4, 0.f};
+                    dst[0] = f2{f[c].f0, f[c].f1}; dst[1] = f2{f[c].f2_, f[c].f3}; dst[2] = f2{f[c].f4, 0.f};
                 }
                 if (lane < 6) {                                         // columns x0-6 .. x0-1 and x0+128 .. x0+133 never hold map values
                     f2* z0 = fbuf + lane * 3;
@@ -485,37 +482,26 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
                     }
 #pragma unroll
                     for (int q = 0; q < 12; ++q) {
-                        w[q].f01 = f2{t[6 * (q + 1)], t[6 * (q + 1) + 1]};
-                        w[q].f23 = f2{t[6 * (q + 1) + 2], t[6 * (q + 1) + 3]};
-                        w[q].f4 = t[6 * (q + 1) + 4];
+                        w[q] = F5{t[6 * (q + 1)], t[6 * (q + 1) + 1], t[6 * (q + 1) + 2], t[6 * (q + 1) + 3], t[6 * (q + 1) + 4]};
                     }
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-                    float s4 = 0.f;
+                    F5 acc = f5_zero();
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) {
-                        const float g = tp.g[k];
-                        s01 += g * w[c + k].f01; s23 += g * w[c + k].f23; s4 += g * w[c + k].f4;
-                    }
-                    ring2[j][c].f01 = s01; ring2[j][c].f23 = s23; ring2[j][c].f4 = s4;
+                    for (int k = 0; k < 11; ++k) f5_axpy(acc, tp.g[k], w[c + k]);
+                    ring2[j][c] = acc;
                 }
                 // stage 2 column pass -> gradient row yo2
                 if (yo2 >= it.r0 && cout) {                              // (yo2 < r1 by construction of y_last)
                     f2 oa, ob;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        f2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
-                        float s4 = 0.f;
+                        F5 acc = f5_zero();
 #pragma unroll
-                        for (int k = 0; k < 11; ++k) {
-                            const F5& h = ring2[(j + 1 + k) % 11][c];
-                            const float g = tp.g[k];
-                            s01 += g * h.f01; s23 += g * h.f23; s4 += g * h.f4;
-                        }
-                        oa[c] = gv * (s01[0] + 2.f * av[c] * s23[0] + bv[c] * s4);
-                        ob[c] = gv * (s01[1] + 2.f * bv[c] * s23[1] + av[c] * s4);
+                        for (int k = 0; k < 11; ++k) f5_axpy(acc, tp.g[k], ring2[(j + 1 + k) % 11][c]);
+                        oa[c] = gv * (acc.f0 + 2.f * av[c] * acc.f2_ + bv[c] * acc.f4);
+                        ob[c] = gv * (acc.f1 + 2.f * bv[c] * acc.f3 + av[c] * acc.f4);
                     }
                     const long off = (long)it.plane * H * W + (long)yo2 * W + xc;
                     if (da) *reinterpret_cast<f2*>(da + off) = oa;

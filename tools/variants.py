@@ -16,7 +16,7 @@ FLAGS = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c
 
 
 def obj(src, out, extra=()):
-    subprocess.run(FLAGS + list(extra) + ["-c", os.path.join(PKG, "csrc", src), "-o", out], check=True)
+    subprocess.run(FLAGS + B.FILE_FLAGS.get(src, []) + list(extra) + ["-c", os.path.join(PKG, "csrc", src), "-o", out], check=True)
     return out
 
 
