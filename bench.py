@@ -56,7 +56,8 @@ def conv_flops(name, a):
     return 2.0 * N * C * IH * IW * M * KH * KW          # transposed: every input pixel meets every tap
 
 
-ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad"}
+ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad",
+          15: "wgrad_x3"}
 KERNEL_OF = {"gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps narrower than 24)",
              "patch": "igemm_patch_kernel (LDS-patch implicit GEMM: 7x7, stride-2, transposed phases)",
              "winograd": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3 forward + input gradient)",
@@ -65,7 +66,8 @@ KERNEL_OF = {"gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps n
              "wgrad_flat": "igemm_wgrad_kernel (flat weight gradient, narrow maps)",
              "wgrad_patch": "wgrad_patch_kernel (LDS-patch weight gradient: stride 2, ragged shapes)",
              "wgrad_s1": "wgrad_s1_kernel (stride-1 weight gradient, staging pipelined inside the MFMA loop)",
-             "m1_wgrad": "conv_m1_wgrad_kernel (64 -> 1 head, VALU)"}
+             "m1_wgrad": "conv_m1_wgrad_kernel (64 -> 1 head, VALU)",
+             "wgrad_x3": "wgrad_x3_kernel (bf16x3 weight gradient, stride-1 3x3: transposed-read X image)"}
 #: share of the algorithmic (direct-convolution) FLOP a family really executes on the matrix pipe
 EXECUTED = {"winograd": 16.0 / 36.0}
 

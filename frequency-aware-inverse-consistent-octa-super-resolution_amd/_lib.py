@@ -19,10 +19,10 @@ _SIG = {
     "conv_wpack_floats": (_L, "iiiiiiii"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
-    "conv2d_wgrad": (_I, "ppp iiiiiiiii i i p"),
+    "conv2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),
     "conv_transpose2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv_transpose2d_dgrad": (_I, "ppp iiiiiiiii i p i i p"),
-    "conv_transpose2d_wgrad": (_I, "ppp iiiiiiiii i i p"),
+    "conv_transpose2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),
     "reflect_pad_bwd": (_I, "pp iiii p"),
     "channel_sum": (_I, "pp iii i p"),
     "bn_workspace_floats": (_L, "i"),

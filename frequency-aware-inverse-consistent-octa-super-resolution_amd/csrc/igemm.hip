@@ -544,8 +544,9 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
 }
 
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
-                          int stride, int pad, int reflect, int accumulate, faoctasr_stream_t stream) {
+                          int stride, int pad, int reflect, int accumulate, int precision, faoctasr_stream_t stream) {
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
+    if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");
     if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
@@ -559,6 +560,11 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     if (OW >= 24) {      // wide maps: LDS-patch weight gradient (atomics into dw, zeroed here unless accumulating)
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
+        if (precision == 2) {      // split-precision operands on the bf16 MFMA where the layer shape allows it
+            rc = launch_wgrad_x3(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
+                                 (hipStream_t)stream);
+            if (rc != 0) { set_route(ROUTE_WGRAD_X3); return rc < 0 ? rc : FAOCTASR_OK; }
+        }
         rc = launch_wgrad_s1(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
                              (hipStream_t)stream);
         if (rc != 0) { set_route(ROUTE_WGRAD_S1); return rc < 0 ? rc : FAOCTASR_OK; }
@@ -598,7 +604,8 @@ int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, 
 }
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,
-                                    int KW, int stride, int pad, int out_pad, int accumulate, faoctasr_stream_t stream) {
+                                    int KW, int stride, int pad, int out_pad, int accumulate, int precision, faoctasr_stream_t stream) {
+    (void)precision;               // (the transposed layers of the model are stride 2: fp32 kernels only, for now)
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;

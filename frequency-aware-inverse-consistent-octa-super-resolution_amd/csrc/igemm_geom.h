@@ -37,6 +37,9 @@ int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s);
 int launch_patch(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s);
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
+// bf16x3 split-precision weight gradient of the stride-1 3x3 layers (wgrad_x3.hip); same contract
+int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
+                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 // stride-1 "same" convolutions on wide maps (wgrad_s1.hip); same contract
 int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);

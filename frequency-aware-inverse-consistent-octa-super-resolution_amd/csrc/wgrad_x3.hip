@@ -1,0 +1,286 @@
+// Split-precision ("bf16x3") weight gradient of the stride-1 3x3 "same" convolutions on the bf16 matrix cores of gfx950 --
+// the weight-gradient counterpart of igemm_bf16x3.hip, selected by TrainStep(precision="bf16x3") (BASELINE configs 3 / 5).
+//
+//   dW[m][c][t] = sum over pixels p=(n,y,x) of  dY[n][m][y][x] * X[n][c][y + kh_t - 1][x + kw_t - 1]
+//
+// Both operands are fp32 activations; each is split into hi = bf16(v), lo = bf16(v - hi) while it is staged, and a product
+// is accumulated in fp32 as hi*hi + hi*lo + lo*hi (three v_mfma_f32_32x32x16_bf16, the dropped lo*lo term is ~2^-16 relative).
+// The MFMA's K dimension is 16 consecutive pixels of a row.  A lane needs 8 consecutive pixels of its row (A = dY) and of
+// its column (B = X shifted by the tap):
+//   * dY is kept [m][pixel] (as in global memory): the A fragment is one aligned ds_read_b128;
+//   * a tap shift would misalign that read for X, so X is kept TRANSPOSED, pixel-major and channel-minor ([pixel][32 channels],
+//     64 bytes per pixel), and the B fragment is two ds_read_b64_tr_b16: the hardware transpose read takes a free row (= pixel)
+//     address from each lane, so a tap is a constant byte offset, and delivers to each lane its channel's 4 pixels.  Four
+//     consecutive pixels x 32 channels tile the 64 LDS banks exactly: the reads are conflict-free without swizzle, and every
+//     fragment address is one per-lane base plus an immediate.
+// Block = 256 threads, tile 64 rows (m) x 64 channels x 9 taps, pixel tile 2 rows x 32; wave (mh, cb) owns 32 rows x one
+// 32-channel block x 9 taps (144 accumulator registers).  Staging: 4x4 (channel x pixel) register blocks are converted with
+// v_cvt_pk_bf16_f32 across two CHANNELS at a time, so a pixel's four channels are already packed for one ds_write_b64.
+// The epilogue turns the accumulators ([m][channel] per tap) into dW's [m][c][t] order through LDS so that the atomics
+// into the gradient arena are contiguous runs.  LDS is single buffered (59 KiB, two blocks per CU alternate their phases).
+#include <type_traits>
+
+#include "common.h"
+
+namespace faoctasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgX3Geom {
+    int N, C, H, W, M;
+    long wsm, wsc;           // dW element strides of row m / channel c (9 taps contiguous)
+    int tiles_x, tiles_y, tiles_per_block;
+    int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges
+};
+
+constexpr int X3_DLD = 72;                         // dY row stride in LDS (bf16): 144 B rows, conflict-free ds_read_b128
+constexpr int X3_PROWS = 4, X3_PCOLS = 40;         // patch: 2 + 2 rows, ten 4-pixel chunks [x0-4, x0+36)
+constexpr int X3_PPIX = X3_PROWS * X3_PCOLS;       // 160 pixels per channel block
+constexpr unsigned X3_CB_BYTES = X3_PPIX * 64;     // one 32-channel block of one plane
+constexpr unsigned X3_XPLANE = 2 * X3_CB_BYTES;    // hi plane, then lo plane
+constexpr unsigned X3_DPLANE = 64 * X3_DLD * 2;    // dY plane bytes
+constexpr unsigned X3_LDS = 2 * X3_DPLANE + 2 * X3_XPLANE;      // 18432 + 40960 = 59392
+
+template <int I, int N, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        x3_static_for<I + 1, N>(f);
+    }
+}
+
+// (a, b) -> packed bf16 hi pair and lo pair (a in the low half): hi = rne(v), lo = rne(v - hi)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 h = {(__bf16)a, (__bf16)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf2 l = {(__bf16)ra, (__bf16)rb};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                          const WgX3Geom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int mh = wave & 1, cb = wave >> 1;                            // the wave's 32 rows and 32-channel block
+
+    const int per_slice = g.gx * g.gy;
+    const int bid = blockIdx.x;
+    const int nfull = (g.slices / 8) * 8 * per_slice;                    // ids below this: the blocks of one slice share an XCD
+    int slice, inner;
+    if (bid < nfull) {
+        const int xcd = bid & 7, k = bid >> 3;
+        inner = k % per_slice;
+        slice = (k / per_slice) * 8 + xcd;
+    } else {
+        const int r = bid - nfull;
+        inner = r % per_slice;
+        slice = (g.slices / 8) * 8 + r / per_slice;
+    }
+    const int c0 = (inner % g.gx) * 64, m0 = (inner / g.gx) * 64;
+    const long hw = (long)g.H * g.W;
+    const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
+    const long tile0 = (long)slice * g.tiles_per_block;
+    long tile1 = tile0 + g.tiles_per_block;
+    tile1 = tile1 < ntiles ? tile1 : ntiles;
+    if (tile0 >= tile1) return;
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned d_lds0 = lds0, x_lds0 = lds0 + 2 * X3_DPLANE;
+
+    // ---- staging maps (tile-invariant) ----------------------------------------------------------------------------------------
+    // dY item i (2 per thread): row m = it >> 3, chunk = it & 7 -> tile row chunk >> 2, pixels 8 (chunk & 3) .. +7
+    unsigned dg_off[2], dl_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + 256 * i, m = it >> 3, ch = it & 7;
+        dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
+        dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
+    }
+    // X item i (3 per thread, 640 used): a 4-channel x 4-pixel register block = channel quad q8 of block cbs, patch row, chunk ck.
+    // Lane bits: q8 fastest, then the chunk.  A pixel is only 64 bytes, so the 16 lanes of a ds_write_b64 group cannot all hit
+    // different banks: with the 8 quads on consecutive lanes a group is 8 quads x 2 chunks (256 bytes apart) = 2-way, against 8-way
+    // with the chunks on consecutive lanes; a wave's global loads still cover 8 rows x 128 contiguous bytes per instruction.
+    unsigned xg_off[3], xl_off[3];
+    int x_row[3], x_ck[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int it = tid + 256 * i;
+        const int q8 = it & 7, cklo = (it >> 3) & 7, rest = it >> 6;     // rest 0..7: (cbs, row) with chunks 0..7; rest 8..9: chunks 8, 9 of all rows
+        int cbs, row, ck;
+        if (rest < 8) { cbs = rest & 1; row = rest >> 1; ck = cklo; }
+        else { cbs = rest & 1; row = cklo >> 1; ck = 8 + (cklo & 1); }
+        const bool use = rest < 10;
+        x_row[i] = use ? row : -1;
+        x_ck[i] = ck;
+        xg_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw + row * g.W + 4 * ck);
+        xl_off[i] = x_lds0 + (unsigned)cbs * X3_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+    }
+
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
+    // A: row mh*32 + l31, pixels (row kb >> 1, 16 (kb & 1) + 8 lh + 0..7)
+    const unsigned a_addr = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
+    // B (transpose read): 16-lane group: channel half (lane >> 4) & 1, lane-in-group = 4 q + p supplies pixel row q, channels 4 p..+3
+    const int gi = lane & 15, q4 = gi >> 2, p4 = gi & 3, chh = (lane >> 4) & 1;
+    const unsigned b_addr = x_lds0 + (unsigned)cb * X3_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int tn, ty, tx;
+    {
+        const long per_img = (long)g.tiles_y * g.tiles_x;
+        tn = (int)(tile0 / per_img);
+        const int r = (int)(tile0 - (long)tn * per_img);
+        ty = r / g.tiles_x;
+        tx = r - ty * g.tiles_x;
+    }
+
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const int y0 = ty * 2, x0 = tx * 32;
+        const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
+        const float* xsrc = x + ((long)tn * g.C + c0) * hw + (long)(y0 - 1) * g.W + (x0 - 4);
+        if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
+
+        // ---- stage: global -> registers -> (hi, lo) bf16 -> LDS ----
+        f32x4 dv[2][2], xv[3][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
+            dv[i][0] = *reinterpret_cast<const f32x4*>(p);
+            dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = y0 - 1 + x_row[i], gx0 = x0 - 4 + 4 * x_ck[i];
+            const bool ok = x_row[i] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;      // zero padding: row / chunk outside
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xsrc + (long)c * hw) + xg_off[i]);
+            }
+        }
+        if (tile != tile0) __syncthreads();                              // every wave has finished reading the previous tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(dv[i][0][0], dv[i][0][1], h0, l0);
+            split2(dv[i][0][2], dv[i][0][3], h1, l1);
+            split2(dv[i][1][0], dv[i][1][1], h2, l2);
+            split2(dv[i][1][2], dv[i][1][3], h3, l3);
+            const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+            const unsigned da = dl_off[i];
+            asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (x_row[i] < 0) continue;
+            const unsigned xa = xl_off[i];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {                             // one pixel's four channels -> 8 bytes per plane
+                unsigned h0, h1, l0, l1;
+                split2(xv[i][0][px], xv[i][1][px], h0, l0);
+                split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3_XPLANE) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- contraction: 4 k-blocks of 16 pixels x 9 taps x 3 split products ----
+        x3_static_for<0, 4>([&](auto kc) {
+            constexpr int kb = decltype(kc)::value;
+            constexpr unsigned a_imm = 2u * (unsigned)((kb >> 1) * 32 + 16 * (kb & 1));
+            bf16x8 a_hi, a_lo;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_hi) : "v"(a_addr), "n"(a_imm));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_lo) : "v"(a_addr), "n"(a_imm + X3_DPLANE));
+            x3_static_for<0, 3>([&](auto hc) {
+                constexpr int kh = decltype(hc)::value;
+                bf16x4 bh[3][2], bl[3][2];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // pixel of k index j: row (kb >> 1) + kh, column 16 (kb & 1) + j + kw + 3 (patch column 0 = image column x0 - 4, pad 1)
+                    const unsigned imm = (unsigned)(((kb >> 1) + kh) * X3_PCOLS + 16 * (kb & 1) + kw + 3) * 64u;
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[kw][0]) : "v"(b_addr), "n"(imm));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[kw][1]) : "v"(b_addr), "n"(imm + 4 * 64));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[kw][0]) : "v"(b_addr), "n"(imm + X3_XPLANE));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[kw][1]) : "v"(b_addr), "n"(imm + 4 * 64 + X3_XPLANE));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_hi), "+v"(a_lo), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[2][0]),
+                             "+v"(bh[2][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[2][0]), "+v"(bl[2][1]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bf16x8 b_hi = __builtin_shufflevector(bh[kw][0], bh[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 b_lo = __builtin_shufflevector(bl[kw][0], bl[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    f32x16& d = acc[kh * 3 + kw];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, d, 0, 0, 0);
+                }
+            });
+        });
+    }
+
+    // ---- epilogue: accumulators [m][channel] per tap -> dW order [m][c][t] through LDS, contiguous atomics ----
+    // per wave and pass: 8 rows x 32 channels x 9 taps = 2304 floats (9216 B); the four waves use disjoint regions
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem) + wave * 2304;
+    const long col_base = (long)(c0 + cb * 32) * g.wsc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                        // rows 8 j .. 8 j + 7 of the wave's 32 = registers 4 j .. 4 j + 3 of both lane halves
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * 9 + t] = acc[t][4 * j + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            const int e = lane + 64 * i;                                 // element of [8 rows][288 = 32 channels x 9 taps]
+            const int row = e / 288, col = e - row * 288;
+            atomicAdd(dw + (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + col, stage[e]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// returns 1 when launched, 0 when the shape is left to the fp32 kernels, <0 on error.  dw zeroed / accumulating, as elsewhere.
+int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
+                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
+    if (stride != 1 || KH != 3 || KW != 3 || pad != 1 || reflect || OH != IH || OW != IW) return 0;
+    if ((C & 63) || (M & 63) || (OW & 31) || (OH & 1) || wsc != 9) return 0;
+    if ((long)64 * IH * IW >= (1L << 29)) return 0;                      // 32-bit byte offsets inside a 64-channel slab
+    WgX3Geom g;
+    g.N = N; g.C = C; g.H = IH; g.W = IW; g.M = M; g.wsm = wsm; g.wsc = wsc;
+    g.tiles_x = OW / 32; g.tiles_y = OH / 2;
+    g.gx = C / 64; g.gy = M / 64;
+    const long ntiles = (long)N * g.tiles_y * g.tiles_x;
+    long slices = 512 / ((long)g.gx * g.gy);
+    if (slices < 1) slices = 1;
+    if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
+    g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
+    g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    lds_optin((const void*)wgrad_x3_kernel, X3_LDS);
+    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(256), X3_LDS, s, x, dy, dw, g);
+    const int rc = check_launch("wgrad_x3");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+}  // namespace faoctasr

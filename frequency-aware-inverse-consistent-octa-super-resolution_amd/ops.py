@@ -133,7 +133,7 @@ class _Conv2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             call("conv2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
-                 reflect, 1 if tgt is not None else 0, st)
+                 reflect, 1 if tgt is not None else 0, conv_precision, st)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
             tgt = _grad_target(ctx.b_ref)
             if tgt is None:
@@ -188,7 +188,7 @@ class _ConvTranspose2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
-                 out_pad, 1 if tgt is not None else 0, st)
+                 out_pad, 1 if tgt is not None else 0, conv_precision, st)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
             tgt = _grad_target(ctx.b_ref)
             if tgt is None:

@@ -28,7 +28,8 @@ int faoctasr_version(void);
 const char* faoctasr_last_error(void);
 /* diagnostics (bench.py's per-family roofline): the kernel family the calling thread's last convolution-type call went to:
  * 1 flat implicit GEMM (narrow maps), 2 LDS-patch implicit GEMM, 3 Winograd F(2x2,3x3), 4 bf16x3 split, 5 M=1 head (VALU);
- * 11 flat weight gradient, 12 LDS-patch weight gradient, 13 stride-1 weight gradient (wgrad_s1), 14 M=1 weight gradient   */
+ * 11 flat weight gradient, 12 LDS-patch weight gradient, 13 stride-1 weight gradient (wgrad_s1), 14 M=1 weight gradient,
+ * 15 bf16x3 weight gradient (wgrad_x3)                                                                                      */
 int faoctasr_last_route(void);
 
 /* ---- convolution family (implicit GEMM on f32 MFMA) --------------------------------------
@@ -57,10 +58,12 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx,
                           int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                           float* wpack, int wpack_state, int precision, faoctasr_stream_t stream);
 /* aten::convolution_backward, weight gradient.  dw[M,C,KH,KW] is overwritten, or added to
- * when accumulate != 0 (the gradient arena is zeroed once per step instead).              */
+ * when accumulate != 0 (the gradient arena is zeroed once per step instead).  precision as above: 2 = bf16x3 (hi/lo-split dY
+ * and X on v_mfma_f32_32x32x16_bf16) for the stride-1 3x3 layers with C, M multiples of 64 and W a multiple of 32; other shapes
+ * silently use the fp32 kernels.                                                            */
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw,
                           int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                          int reflect, int accumulate, faoctasr_stream_t stream);
+                          int reflect, int accumulate, int precision, faoctasr_stream_t stream);
 /* nn.ConvTranspose2d forward: model.py:431 (4x4 s2 p1), 469 (3x3 s2 p1 output_padding 1).
  * x[N,C,IH,IW], w[C,M,KH,KW], y[N,M,OH,OW], OH=(IH-1)*stride-2*pad+KH+out_pad.          */
 int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -72,7 +75,7 @@ int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx,
                                     int out_pad, float* wpack, int wpack_state, int precision, faoctasr_stream_t stream);
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw,
                                     int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
-                                    int out_pad, int accumulate, faoctasr_stream_t stream);
+                                    int out_pad, int accumulate, int precision, faoctasr_stream_t stream);
 /* gradient of nn.ReflectionPad2d(p): dx[NC,H,W] += fold of dxp[NC,H+2p,W+2p] (dx overwritten) */
 int faoctasr_reflect_pad_bwd(const float* dxp, float* dx, int NC, int H, int W, int p, faoctasr_stream_t stream);
 /* per-channel sum over (N,HW): conv bias gradient.  db[C] overwritten (or added to).      */

@@ -77,6 +77,7 @@ CONV_CASES = [
     (3, 64, 6, 32, 64, 3, 1, 1, False, False, None),          # one tile column (left AND right border in one tile), 3 tile rows
     (2, 16, 32, 64, 128, 5, 1, 2, False, True, None),         # 5x5 pad 2, two row blocks
     (5, 24, 8, 64, 64, 3, 1, 1, False, False, None),          # 216 columns: a second, mostly empty slab; odd batch
+    (3, 128, 10, 96, 128, 3, 1, 1, False, False, None),       # two 64-channel slabs x two row blocks (bf16x3 weight gradient: wgrad_x3.hip)
 ]
 
 
@@ -486,20 +487,25 @@ def test_conv2d_bf16x3(fa, case):
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(M, C, k, k, generator=g) * 0.05
     b = torch.randn(M, generator=g) if bias else None
-    xr = x.clone().requires_grad_(True)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     xin = F.pad(xr, (p, p, p, p), mode="reflect") if reflect else xr
-    ref = F.conv2d(xin, w, b, stride=s, padding=0 if reflect else p)
+    ref = F.conv2d(xin, wr, b, stride=s, padding=0 if reflect else p)
     cot = torch.randn(ref.shape, generator=g)
     ref.backward(cot)
     fa.ops.conv_precision = 2
     try:
-        xd = dev(x).requires_grad_(True)
-        out = fa.ops.conv2d(xd, dev(w), dev(b) if bias else None, s, p, reflect, None, 0.2)
+        xd, wd = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+        out = fa.ops.conv2d(xd, wd, dev(b) if bias else None, s, p, reflect, None, 0.2)
         out.backward(dev(cot))
+        route = fa._lib.load().faoctasr_last_route()
     finally:
         fa.ops.conv_precision = 0
     assert rel_l2(out, ref) < 3e-5
     assert rel_l2(xd.grad, xr.grad) < 3e-5
+    # the weight gradient: split-precision kernel (route 15) on the stride-1 3x3 layers with C, M % 64 == 0, W % 32 == 0, even H
+    x3 = k == 3 and s == 1 and p == 1 and not reflect and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0
+    assert (route == 15) == x3, (route, case)
+    assert rel_l2(wd.grad, wr.grad) < 3e-5
     # and it is NOT the plain-bf16 error level (~3e-3)
     close(out, ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()))
 
@@ -607,7 +613,7 @@ def test_conv_kernels_stay_inside_their_buffers(fa, case):
         intact(wp_all, max(nwp, 1), "wpack (kind %d, precision %d)" % (kind, precision))
     dw_all, dw = banded(M * C * k * k)
     dw.zero_()
-    call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, k, k, s, p, 0, 1, st)
+    call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, k, k, s, p, 0, 1, 0, st)
     torch.cuda.synchronize()
     intact(dw_all, M * C * k * k, "dw")
 

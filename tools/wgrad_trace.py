@@ -12,7 +12,7 @@ x = torch.randn(N, C, H, W, device="cuda"); dy = torch.randn(N, M, H, W, device=
 dw = torch.zeros(M, C, 3, 3, device="cuda")
 for _ in range(2):
     dw.zero_()
-    call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, 3, 3, 1, 1, 0, 1, stream_ptr())
+    call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, 3, 3, 1, 1, 0, 1, 0, stream_ptr())
 torch.cuda.synchronize()
 import ctypes, numpy as np
 raw = (ctypes.c_uint * 128)()
