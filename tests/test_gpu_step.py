@@ -179,7 +179,7 @@ def test_inference_path_eval_mode(fa, O):
     nets["A2B"].eval()
     hf, lf = fa.frequency_split(a.cuda(), 10, 8)
     unfolded = nets["A2B"](lf, hf)[2]
-    close(out, unfolded, rtol=1e-4, atol=2e-5)
+    close(out, unfolded.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
     m = fa.evaluate_pairs(nets["A2B"], [(a[:1].cuda(), a[1:].cuda())])
     assert set(m) == {"psnr", "ssim", "mse", "nmi"} and m["mse"] > 0
     y1 = fa.super_resolve(nets["A2B"], a[:1].cuda()).cpu().numpy()[0, 0]
