@@ -56,9 +56,10 @@ def conv_flops(name, a):
     return 2.0 * N * C * IH * IW * M * KH * KW          # transposed: every input pixel meets every tap
 
 
-ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad",
+ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 6: "narrow", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad",
           15: "wgrad_x3"}
-KERNEL_OF = {"gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps narrower than 24)",
+KERNEL_OF = {"narrow": "igemm_nm_kernel (GEMM-shaped implicit GEMM on the packed weights, maps narrower than 24)",
+             "gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps narrower than 24)",
              "patch": "igemm_patch_kernel (LDS-patch implicit GEMM: 7x7, stride-2, transposed phases)",
              "winograd": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3 forward + input gradient)",
              "bf16x3": "igemm_bf16x3_kernel (hi/lo-split operands on v_mfma_f32_32x32x16_bf16)",

@@ -10,7 +10,7 @@ namespace faoctasr {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 // which kernel family the last convolution-type call of this thread was dispatched to (diagnostics: faoctasr_last_route)
-enum Route { ROUTE_NONE = 0, ROUTE_GATHER_FLAT = 1, ROUTE_PATCH = 2, ROUTE_WINOGRAD = 3, ROUTE_BF16X3 = 4, ROUTE_M1_FWD = 5,
+enum Route { ROUTE_NONE = 0, ROUTE_GATHER_FLAT = 1, ROUTE_PATCH = 2, ROUTE_WINOGRAD = 3, ROUTE_BF16X3 = 4, ROUTE_M1_FWD = 5, ROUTE_NARROW = 6,
              ROUTE_WGRAD_FLAT = 11, ROUTE_WGRAD_PATCH = 12, ROUTE_WGRAD_S1 = 13, ROUTE_M1_WGRAD = 14, ROUTE_WGRAD_X3 = 15 };
 void set_route(int r);
 

@@ -470,6 +470,8 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
         }
         rc = launch_patch(x, wpack, bias, y, pg, act, slope, s);
         if (rc != 0) { set_route(ROUTE_PATCH); return rc < 0 ? rc : FAOCTASR_OK; }
+        rc = launch_narrow(x, wpack, bias, y, pg, act, slope, s);
+        if (rc != 0) { set_route(ROUTE_NARROW); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     set_route(ROUTE_GATHER_FLAT);
     return launch_gather(x, w, bias, y, g, act, slope, s);

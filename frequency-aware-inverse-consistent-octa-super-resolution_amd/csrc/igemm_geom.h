@@ -35,6 +35,8 @@ int patch_geom_from(const IgemmGeom& f, PatchGeom& g);
 long patch_pack_floats(const PatchGeom& g);
 int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s);
 int launch_patch(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s);
+// narrow maps (phase width < 24) on the same packed image (igemm_nm.hip): 1 launched, 0 not eligible, <0 error
+int launch_narrow(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s);
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 // bf16x3 split-precision weight gradient of the stride-1 3x3 layers (wgrad_x3.hip); same contract

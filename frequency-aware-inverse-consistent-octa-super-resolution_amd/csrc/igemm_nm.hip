@@ -1,0 +1,183 @@
+// Implicit-GEMM convolution for NARROW maps (output phase width < 24: the discriminators' 16x16 ... 2x2 layers) on the exact-f32
+// MFMA of gfx950: conv forward, conv input gradient, transposed-conv forward / input gradient through the same tap-list
+// geometry as igemm_patch.hip, reading the SAME packed weight image.
+//
+// These layers are plain GEMMs with a gathered B operand -- Y[M][pixels] = Wp[K][M]^T . im2col(X)[K][pixels] with M = 256..512,
+// K = C * taps = 2048..8192, pixels = batch * OH * OW = 72..2048 -- and ran on the flat kernel of igemm.hip (K chunks of 16, two
+// barriers and 24 scalar loads / stores per 16 MFMAs and wave, per-element index arithmetic on the weights: 0.20 of the MFMA
+// peak, 8.3 ms per train step).  Here:
+//   * K advances in the pack's own chunks of KR = kc * taps = 64 rows, 128 rows (m) x 64 pixels per block: 64 MFMAs per wave between
+//     barriers;
+//   * A = the packed weights Wp[chunk][r = tap * kc + c][Mpad]: a slab row is 512 contiguous bytes, 8 global_load_dwordx4 + 8
+//     ds_write_b128 per thread and chunk, no index arithmetic;
+//   * B is gathered with buffer loads whose 16 per-thread offsets (tap displacement + channel plane, or out of range = zero
+//     padding) are computed ONCE -- a thread keeps its pixel for the whole K loop -- and the chunk's channel advance is the scalar
+//     offset of the instruction: no vector arithmetic per element;
+//   * both operands are register-prefetched one chunk ahead (LDS single buffered, 48 KiB: three blocks per CU);
+//   * split-K over chunks when the tile grid cannot fill the chip (fp32 atomics into a zeroed output, as before).
+#include <type_traits>
+
+#include "common.h"
+#include "igemm_geom.h"
+
+namespace faoctasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NM_MT = 128, NM_NT = 64, NM_KR = 64;
+
+__global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                       float* __restrict__ y, const PatchGeom g, const int ksplit) {
+    __shared__ __attribute__((aligned(16))) float A_s[NM_KR * NM_MT];    // [r][m]
+    __shared__ __attribute__((aligned(16))) float B_s[NM_KR * NM_NT];    // [r][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
+    const int GH = g.gh[ph], GW = g.gw[ph];
+    const long npix = (long)g.N * GH * GW;
+    const long j0 = (long)blockIdx.x * NM_NT;
+    if (j0 >= npix) return;
+    const int m0 = blockIdx.y * NM_MT;
+    const int t0 = g.t0[ph], T = g.t0[ph + 1] - t0, kc = g.kc[ph];       // kc * T == NM_KR (checked by the launcher)
+    const int nchunks = g.C / kc;                                        // C % kc == 0 (checked)
+    const int cps = (nchunks + ksplit - 1) / ksplit;
+    const int ch0 = ks * cps;
+    int ch1 = ch0 + cps;
+    ch1 = ch1 < nchunks ? ch1 : nchunks;
+    if (ch0 >= ch1) return;
+    const long chw = (long)g.IH * g.IW;
+
+    // ---- B gather: this thread's pixel and its 16 rows r = rg + 4 i of every chunk ----
+    const int jj = tid & 63, rg = tid >> 6;
+    const long j = j0 + jj;
+    unsigned boff[16];
+    {
+        constexpr unsigned OOB = 0x80000000u;
+        int n = 0, a = 0, b = 0;
+        const bool jv = j < npix;
+        if (jv) {
+            n = (int)(j / ((long)GH * GW));
+            const int r = (int)(j - (long)n * GH * GW);
+            a = r / GW;
+            b = r - a * GW;
+        }
+        const long img = (long)n * g.C * chw;                            // element offset of the image; < 2^29 checked by the launcher
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = rg + 4 * i, t = r / kc, cl = r - t * kc;
+            const int tp = g.taps[t0 + t];
+            int iy = a * g.SI + (tp & 0xff) + g.oy0[ph], ix = b * g.SI + ((tp >> 8) & 0xff) + g.ox0[ph];
+            if (g.reflect) {
+                iy = iy < 0 ? -iy : iy; iy = iy >= g.IH ? 2 * g.IH - 2 - iy : iy;
+                ix = ix < 0 ? -ix : ix; ix = ix >= g.IW ? 2 * g.IW - 2 - ix : ix;
+            }
+            const bool ok = jv && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+            boff[i] = ok ? 4u * (unsigned)(img + (long)cl * chw + (long)iy * g.IW + ix) : OOB;
+        }
+    }
+    const long x_bytes = (long)g.N * g.C * chw * 4;
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)(x_bytes < 0x7ffffff0L ? x_bytes : 0x7ffffff0L), 0x00020000);
+    // ---- A slab: 64 rows x 128 floats = 2048 float4; thread piece i = tid + 256 i: row = piece >> 5, 16-byte column = piece & 31 ----
+    const float* wslab = wp + g.pack_off[ph] + (long)m0;
+    const long slab_stride = (long)NM_KR * g.Mpad;                       // floats per chunk
+
+    f32x4 ra[8];
+    float rb[16];
+    auto load_chunk = [&](int ch) {
+        const float* ws = wslab + (long)ch * slab_stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = tid + 256 * i;
+            ra[i] = *reinterpret_cast<const f32x4*>(ws + (long)(piece >> 5) * g.Mpad + (piece & 31) * 4);
+        }
+        const int soff = (int)(4L * ch * kc * chw);                      // the chunk's first channel plane (scalar)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, boff[i], soff, 0));
+    };
+
+    // 4 waves = 2 (rows) x 2 (pixels): wave tile 64 rows x 32 pixels
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    load_chunk(ch0);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        if (ch != ch0) __syncthreads();                                  // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(A_s + (piece >> 5) * NM_MT + (piece & 31) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) B_s[(rg + 4 * i) * NM_NT + jj] = rb[i];
+        __syncthreads();
+        if (ch + 1 < ch1) load_chunk(ch + 1);                            // in flight under the MFMAs below
+        const float* ap = A_s + wm * 64 + l31 + lh * NM_MT;
+        const float* bp = B_s + wn * 32 + l31 + lh * NM_NT;
+#pragma unroll
+        for (int kk = 0; kk < NM_KR; kk += 2) {
+            const float a0 = ap[kk * NM_MT], a1 = ap[kk * NM_MT + 32], b0 = bp[kk * NM_NT];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+    const long jo = j0 + wn * 32 + l31;
+    if (jo >= npix) return;
+    const int no = (int)(jo / ((long)GH * GW));
+    const int r0 = (int)(jo - (long)no * GH * GW);
+    const int ao = r0 / GW, bo = r0 - ao * GW;
+    const long ohw = (long)g.OH * g.OW;
+    const long obase = (long)no * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int m = m0 + wm * 64 + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+            if (m < g.M) {
+                float v = acc[mi][rr];
+                if (bias && ks == 0) v += bias[m];
+                if (ksplit > 1) atomicAdd(y + obase + (long)m * ohw, v);
+                else y[obase + (long)m * ohw] = act_apply(v, g.act, g.slope);
+            }
+        }
+}
+
+// returns 1 when launched, 0 when the shape is left to the flat kernel, <0 on error.  `wp` must hold the packed image of
+// launch_pack (igemm_patch.hip) for this geometry.
+int launch_narrow(const float* x, const float* wp, const float* bias, float* y, PatchGeom& g, int act, float slope, hipStream_t s) {
+    g.act = act; g.slope = slope;
+    if (g.M < 64 || (long)g.N * g.C * g.IH * g.IW >= (1L << 29)) return 0;
+    long maxpix = 0;
+    int minchunks = 1 << 30;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int T = g.t0[p + 1] - g.t0[p];
+        if (T <= 0 || g.kc[p] * T != NM_KR || g.C % g.kc[p] != 0) return 0;
+        const long np = (long)g.N * g.gh[p] * g.gw[p];
+        maxpix = np > maxpix ? np : maxpix;
+        const int nc = g.C / g.kc[p];
+        minchunks = nc < minchunks ? nc : minchunks;
+    }
+    if (maxpix == 0) return 0;
+    const long gx = (maxpix + NM_NT - 1) / NM_NT, gy = (g.M + NM_MT - 1) / NM_MT;
+    const long blocks = gx * gy * g.nphase;
+    // split K until ~2 blocks per CU exist, each still reducing >= 4 chunks; every split adds one atomic pass over the output
+    int ksplit = 1;
+    if (act == FAOCTASR_ACT_NONE && blocks < 384) {
+        ksplit = (int)((512 + blocks - 1) / blocks);
+        if (ksplit > minchunks / 4) ksplit = minchunks / 4;
+        if (ksplit < 1) ksplit = 1;
+    }
+    if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
+        return fail(FAOCTASR_EHIP, "memset y failed");
+    hipLaunchKernelGGL(igemm_nm_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)(g.nphase * ksplit)), dim3(256), 0, s, x, wp, bias, y, g, ksplit);
+    const int rc = check_launch("igemm_nm");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+}  // namespace faoctasr
