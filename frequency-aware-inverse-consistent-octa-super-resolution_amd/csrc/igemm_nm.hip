@@ -25,8 +25,19 @@ namespace faoctasr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NM_MT = 128, NM_NT = 64, NM_KR = 64;
+constexpr int NM_MT = 128, NM_NT = 64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+template <int I, int N, class F>
+__device__ __forceinline__ void nm_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        nm_static_for<I + 1, N>(f);
+    }
+}
+
+// NM_KR = rows of a packed chunk (kc * taps): 64 or 32
+template <int NM_KR>
 __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                                                        float* __restrict__ y, const PatchGeom g, const int ksplit) {
     __shared__ __attribute__((aligned(16))) float A_s[NM_KR * NM_MT];    // [r][m]
@@ -40,6 +51,7 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
     if (j0 >= npix) return;
     const int m0 = blockIdx.y * NM_MT;
     const int t0 = g.t0[ph], T = g.t0[ph + 1] - t0, kc = g.kc[ph];       // kc * T == NM_KR (checked by the launcher)
+    (void)T;
     const int nchunks = g.C / kc;                                        // C % kc == 0 (checked)
     const int cps = (nchunks + ksplit - 1) / ksplit;
     const int ch0 = ks * cps;
@@ -51,7 +63,8 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
     // ---- B gather: this thread's pixel and its 16 rows r = rg + 4 i of every chunk ----
     const int jj = tid & 63, rg = tid >> 6;
     const long j = j0 + jj;
-    unsigned boff[16];
+    constexpr int NB = NM_KR / 4, NA = NM_KR / 8;                        // B dwords / A float4 staged per thread and chunk
+    unsigned boff[NB];
     {
         constexpr unsigned OOB = 0x80000000u;
         int n = 0, a = 0, b = 0;
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
         }
         const long img = (long)n * g.C * chw;                            // element offset of the image; < 2^29 checked by the launcher
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int r = rg + 4 * i, t = r / kc, cl = r - t * kc;
             const int tp = g.taps[t0 + t];
             int iy = a * g.SI + (tp & 0xff) + g.oy0[ph], ix = b * g.SI + ((tp >> 8) & 0xff) + g.ox0[ph];
@@ -82,18 +95,18 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
     const float* wslab = wp + g.pack_off[ph] + (long)m0;
     const long slab_stride = (long)NM_KR * g.Mpad;                       // floats per chunk
 
-    f32x4 ra[8];
-    float rb[16];
+    f32x4 ra[NA];
+    float rb[NB];
     auto load_chunk = [&](int ch) {
         const float* ws = wslab + (long)ch * slab_stride;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int piece = tid + 256 * i;
             ra[i] = *reinterpret_cast<const f32x4*>(ws + (long)(piece >> 5) * g.Mpad + (piece & 31) * 4);
         }
         const int soff = (int)(4L * ch * kc * chw);                      // the chunk's first channel plane (scalar)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, boff[i], soff, 0));
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrd, boff[i], soff, 0));
     };
 
     // 4 waves = 2 (rows) x 2 (pixels): wave tile 64 rows x 32 pixels
@@ -104,26 +117,63 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
+    // fragment addresses: A_s[k][m] and B_s[k][pixel] with k = kk + lh; one ds_read2st64_b32 (two rows 2 k-steps apart ... see rd)
+    const unsigned lds_a = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)A_s + 4u * (unsigned)(wm * 64 + l31 + lh * NM_MT);
+    const unsigned lds_b = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)B_s + 4u * (unsigned)(wn * 32 + l31 + lh * NM_NT);
+    // a "quad" = 4 k-steps (8 rows).  ds_read2st64_b32 reads two dwords 64-dword units apart: A rows are 128 floats (2 units), B rows
+    // 64 floats (1 unit), so one instruction fetches the operand of k-steps (j, j+1).  6 LDS instructions per 8 MFMAs, issued one
+    // quad ahead with a counted wait (the compiler's own schedule waited lgkmcnt(0) before every MFMA pair).
+    constexpr int NQ = NM_KR / 8;
+    f32x2 A0[2][2], A1[2][2], Bq0[2], Bq1[2];                            // [row block mi][k-step pair], [k-step pair]
+    auto rd = [&](auto qc, f32x2 (&A)[2][2], f32x2 (&B)[2]) {
+        constexpr int q = decltype(qc)::value;
+        const unsigned la0 = lds_a, la1 = lds_a + 128u, lb = lds_b;       // (asm operands cannot name the enclosing function's variables)
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(A[0][0]) : "v"(la0), "n"(2 * (8 * q)), "n"(2 * (8 * q + 2)));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(A[1][0]) : "v"(la1), "n"(2 * (8 * q)), "n"(2 * (8 * q + 2)));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(B[0]) : "v"(lb), "n"(8 * q), "n"(8 * q + 2));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(A[0][1]) : "v"(la0), "n"(2 * (8 * q + 4)), "n"(2 * (8 * q + 6)));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(A[1][1]) : "v"(la1), "n"(2 * (8 * q + 4)), "n"(2 * (8 * q + 6)));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(B[1]) : "v"(lb), "n"(8 * q + 4), "n"(8 * q + 6));
+    };
+    auto wait_set = [&](f32x2 (&A)[2][2], f32x2 (&B)[2], auto yc) {
+        constexpr int younger = decltype(yc)::value;
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(B[0]), "+v"(B[1]) : "n"(younger));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto quad = [&](auto qc, f32x2 (&A)[2][2], f32x2 (&B)[2], f32x2 (&An)[2][2], f32x2 (&Bn)[2]) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q + 1 < NQ) {
+            rd(std::integral_constant<int, q + 1>{}, An, Bn);
+            wait_set(A, B, std::integral_constant<int, 6>{});
+        } else {
+            wait_set(A, B, std::integral_constant<int, 0>{});
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0][st >> 1][st & 1], B[st >> 1][st & 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1][st >> 1][st & 1], B[st >> 1][st & 1], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     load_chunk(ch0);
     for (int ch = ch0; ch < ch1; ++ch) {
         if (ch != ch0) __syncthreads();                                  // the previous chunk's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int piece = tid + 256 * i;
             *reinterpret_cast<f32x4*>(A_s + (piece >> 5) * NM_MT + (piece & 31) * 4) = ra[i];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) B_s[(rg + 4 * i) * NM_NT + jj] = rb[i];
+        for (int i = 0; i < NB; ++i) B_s[(rg + 4 * i) * NM_NT + jj] = rb[i];
         __syncthreads();
         if (ch + 1 < ch1) load_chunk(ch + 1);                            // in flight under the MFMAs below
-        const float* ap = A_s + wm * 64 + l31 + lh * NM_MT;
-        const float* bp = B_s + wn * 32 + l31 + lh * NM_NT;
-#pragma unroll
-        for (int kk = 0; kk < NM_KR; kk += 2) {
-            const float a0 = ap[kk * NM_MT], a1 = ap[kk * NM_MT + 32], b0 = bp[kk * NM_NT];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
-        }
+        rd(std::integral_constant<int, 0>{}, A0, Bq0);
+        nm_static_for<0, NQ / 2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            quad(std::integral_constant<int, 2 * h>{}, A0, Bq0, A1, Bq1);
+            quad(std::integral_constant<int, 2 * h + 1>{}, A1, Bq1, A0, Bq0);
+        });
     }
 
     // ---- epilogue: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
@@ -155,14 +205,18 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
     if (g.M < 64 || (long)g.N * g.C * g.IH * g.IW >= (1L << 29)) return 0;
     long maxpix = 0;
     int minchunks = 1 << 30;
+    int KR = 0;
     for (int p = 0; p < g.nphase; ++p) {
         const int T = g.t0[p + 1] - g.t0[p];
-        if (T <= 0 || g.kc[p] * T != NM_KR || g.C % g.kc[p] != 0) return 0;
+        if (T <= 0 || g.C % g.kc[p] != 0) return 0;
+        if (p == 0) KR = g.kc[p] * T;
+        if (g.kc[p] * T != KR) return 0;
         const long np = (long)g.N * g.gh[p] * g.gw[p];
         maxpix = np > maxpix ? np : maxpix;
         const int nc = g.C / g.kc[p];
         minchunks = nc < minchunks ? nc : minchunks;
     }
+    if (KR != 64 && KR != 32) return 0;
     if (maxpix == 0) return 0;
     const long gx = (maxpix + NM_NT - 1) / NM_NT, gy = (g.M + NM_MT - 1) / NM_MT;
     const long blocks = gx * gy * g.nphase;
@@ -175,7 +229,9 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
     }
     if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
         return fail(FAOCTASR_EHIP, "memset y failed");
-    hipLaunchKernelGGL(igemm_nm_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)(g.nphase * ksplit)), dim3(256), 0, s, x, wp, bias, y, g, ksplit);
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(g.nphase * ksplit));
+    if (KR == 64) hipLaunchKernelGGL(igemm_nm_kernel<64>, grid, dim3(256), 0, s, x, wp, bias, y, g, ksplit);
+    else hipLaunchKernelGGL(igemm_nm_kernel<32>, grid, dim3(256), 0, s, x, wp, bias, y, g, ksplit);
     const int rc = check_launch("igemm_nm");
     return rc == FAOCTASR_OK ? 1 : rc;
 }
