@@ -42,7 +42,12 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
                                                        float* __restrict__ y, const PatchGeom g, const int ksplit) {
     __shared__ __attribute__((aligned(16))) float A_s[NM_KR * NM_MT];    // [r][m]
     __shared__ __attribute__((aligned(16))) float B_s[NM_KR * NM_NT];    // [r][pixel]
+    __shared__ int taps_s[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the tap table through LDS: indexing the by-value kernel argument with a per-thread index compiles to one dependent global load
+    // per tap (16 serialised round trips before the first chunk: several microseconds of a block that lives for ~20)
+    if (tid < 64) taps_s[tid] = g.taps[tid];
+    __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
     const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int r = rg + 4 * i, t = r / kc, cl = r - t * kc;
-            const int tp = g.taps[t0 + t];
+            const int tp = taps_s[t0 + t];
             int iy = a * g.SI + (tp & 0xff) + g.oy0[ph], ix = b * g.SI + ((tp >> 8) & 0xff) + g.ox0[ph];
             if (g.reflect) {
                 iy = iy < 0 ? -iy : iy; iy = iy >= g.IH ? 2 * g.IH - 2 - iy : iy;
@@ -220,10 +225,11 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
     if (maxpix == 0) return 0;
     const long gx = (maxpix + NM_NT - 1) / NM_NT, gy = (g.M + NM_MT - 1) / NM_MT;
     const long blocks = gx * gy * g.nphase;
-    // split K until ~2 blocks per CU exist, each still reducing >= 4 chunks; every split adds one atomic pass over the output
+    // split K until ~1.5 blocks per CU exist, each still reducing >= 4 chunks; every split adds one atomic pass over the output
+    // (1.3 TB/s chip-wide) and one block prologue
     int ksplit = 1;
     if (act == FAOCTASR_ACT_NONE && blocks < 384) {
-        ksplit = (int)((512 + blocks - 1) / blocks);
+        ksplit = (int)((384 + blocks - 1) / blocks);
         if (ksplit > minchunks / 4) ksplit = minchunks / 4;
         if (ksplit < 1) ksplit = 1;
     }
