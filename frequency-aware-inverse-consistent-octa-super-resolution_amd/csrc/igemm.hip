@@ -313,26 +313,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         }
         __syncthreads();
         if (ch + 1 < ch_end) load_chunk(ch + 1);
-        // all 16 fragment pairs of the chunk are requested up front (ds_read2_b32: k-steps j and j+1 of one operand per instruction)
-        // and retired with counted waits, so that only the first pair's LDS latency is exposed (the compiler's own schedule waited
-        // lgkmcnt(0) before every MFMA: 0.17 of the MFMA peak)
-        {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const unsigned la = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)A_s + 4u * (unsigned)((wm * 32 + l31) * LD + lh);
-            const unsigned lb = (unsigned)(unsigned long)(__attribute__((address_space(3))) float*)B_s + 4u * (unsigned)((wn * 32 + l31) * LD + lh);
-            f32x2 fa[8], fb[8];
-#define WG_RD(i) \
-            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(fa[i]) : "v"(la), "n"(4 * (i)), "n"(4 * (i) + 2)); \
-            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(fb[i]) : "v"(lb), "n"(4 * (i)), "n"(4 * (i) + 2));
-            WG_RD(0) WG_RD(1) WG_RD(2) WG_RD(3) WG_RD(4) WG_RD(5) WG_RD(6) WG_RD(7)
-#undef WG_RD
-#define WG_MM(i, cnt) \
-            asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fa[i]), "+v"(fb[i])); \
-            __builtin_amdgcn_sched_barrier(0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][0], fb[i][0], acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][1], fb[i][1], acc, 0, 0, 0);
-            WG_MM(0, 14) WG_MM(1, 12) WG_MM(2, 10) WG_MM(3, 8) WG_MM(4, 6) WG_MM(5, 4) WG_MM(6, 2) WG_MM(7, 0)
-#undef WG_MM
+#pragma unroll
+        for (int kk0 = 0; kk0 < PJ; kk0 += 2) {
+            const float af = A_s[(wm * 32 + l31) * LD + kk0 + lh];
+            const float bf = B_s[(wn * 32 + l31) * LD + kk0 + lh];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
         }
     }
     // epilogue: row (m) from the register index, column (c,t) from the lane

@@ -225,11 +225,11 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
     if (maxpix == 0) return 0;
     const long gx = (maxpix + NM_NT - 1) / NM_NT, gy = (g.M + NM_MT - 1) / NM_MT;
     const long blocks = gx * gy * g.nphase;
-    // split K until ~1.5 blocks per CU exist, each still reducing >= 4 chunks; every split adds one atomic pass over the output
+    // split K until ~2 blocks per CU exist, each still reducing >= 4 chunks; every split adds one atomic pass over the output
     // (1.3 TB/s chip-wide) and one block prologue
     int ksplit = 1;
     if (act == FAOCTASR_ACT_NONE && blocks < 384) {
-        ksplit = (int)((384 + blocks - 1) / blocks);
+        ksplit = (int)((512 + blocks - 1) / blocks);
         if (ksplit > minchunks / 4) ksplit = minchunks / 4;
         if (ksplit < 1) ksplit = 1;
     }
