@@ -110,9 +110,123 @@ __global__ __launch_bounds__(256) void conv_m1_wgrad_kernel(const float* __restr
     if (mine) atomicAdd(dw + (long)(c0 + cl) * T + t, acc);
 }
 
+// ---- 3x3 fast forms (round 2): no LDS, no barrier ---------------------------------------------------------------------------
+// The LDS-patch kernels above read two LDS words per FMA (158 / 174 us for the 64 -> 1 head at 256^2, batch 8: 0.85 TB/s on a
+// 134 MB read).  For the 3x3 head a thread owns 4 adjacent pixels of a row; per (channel, input row) it loads its aligned float4 and
+// the two neighbouring columns (L1 hits), the weights arrive through the scalar cache (uniform index), and the 36 FMAs per channel
+// run out of registers.  W % 4 == 0.
+typedef float m1f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void m1_row6(const float* __restrict__ row, int xq, int W, bool rowok, float (&v)[6]) {
+    // v[0..5] = columns xq-1 .. xq+4 of `row`, zero outside the image
+    m1f4 c = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f, r = 0.f;
+    if (rowok) {
+        c = *reinterpret_cast<const m1f4*>(row + xq);
+        if (xq > 0) l = row[xq - 1];
+        if (xq + 4 < W) r = row[xq + 4];
+    }
+    v[0] = l; v[1] = c[0]; v[2] = c[1]; v[3] = c[2]; v[4] = c[3]; v[5] = r;
+}
+
+__global__ __launch_bounds__(256) void conv_m1_fwd3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int N, int C, int H, int W, int act, float slope) {
+    const int wq = W >> 2;                                              // 4-pixel groups per row
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;             // (n, row, group)
+    const long total = (long)N * H * wq;
+    if (item >= total) return;
+    const int xq = (int)(item % wq) * 4;
+    const long t = item / wq;
+    const int oy = (int)(t % H), n = (int)(t / H);
+    const long hw = (long)H * W;
+    const float* xn = x + (long)n * C * hw;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float* wc = w + c * 9;                                    // uniform: scalar loads
+        const float* xc = xn + (long)c * hw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy - 1 + kh;
+            float v[6];
+            m1_row6(xc + (long)iy * W, xq, W, (unsigned)iy < (unsigned)H, v);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float wv = wc[kh * 3 + kw];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] += wv * v[p + kw];
+            }
+        }
+    }
+    const float b = bias ? bias[0] : 0.f;
+    m1f4 o = {act_apply(acc[0] + b, act, slope), act_apply(acc[1] + b, act, slope), act_apply(acc[2] + b, act, slope), act_apply(acc[3] + b, act, slope)};
+    *reinterpret_cast<m1f4*>(y + (long)n * hw + (long)oy * W + xq) = o;
+}
+
+// weight gradient: a wave owns (image n, 4 channels, a segment of rows); lane = 4-pixel column group (strided over the row).  The
+// three most recent input rows of each channel live in a register ring, so every x element is loaded once; 36 accumulators (4
+// channels x 9 taps) per lane are summed over the wave at the end and added atomically (one lane per value).
+constexpr int M1W_CH = 4, M1W_ROWS = 32;
+__global__ __launch_bounds__(256) void conv_m1_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int N,
+                                                             int C, int H, int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cgroups = (C + M1W_CH - 1) / M1W_CH, rsegs = (H + M1W_ROWS - 1) / M1W_ROWS;
+    const long item = (long)blockIdx.x * 4 + wave;                      // (n, row segment, channel group)
+    if (item >= (long)N * rsegs * cgroups) return;                       // whole waves only; no barrier in this kernel
+    const int cg = (int)(item % cgroups);
+    const long t = item / cgroups;
+    const int rs = (int)(t % rsegs), n = (int)(t / rsegs);
+    const int c0 = cg * M1W_CH, r0 = rs * M1W_ROWS, r1 = r0 + M1W_ROWS < H ? r0 + M1W_ROWS : H;
+    const long hw = (long)H * W;
+    const float* dyn = dy + (long)n * hw;
+    float acc[M1W_CH][9];
+#pragma unroll
+    for (int c = 0; c < M1W_CH; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
+    for (int xq = lane * 4; xq < W; xq += 256) {
+        float ring[M1W_CH][3][6];                                        // rows oy-1, oy, oy+1 of each channel
+#pragma unroll
+        for (int c = 0; c < M1W_CH; ++c) {
+            const bool cok = c0 + c < C;
+            const float* xc = x + ((long)n * C + (cok ? c0 + c : 0)) * hw;
+            m1_row6(xc + (long)(r0 - 1) * W, xq, W, cok && r0 - 1 >= 0, ring[c][0]);
+            m1_row6(xc + (long)r0 * W, xq, W, cok, ring[c][1]);
+        }
+        for (int oy = r0; oy < r1; ++oy) {
+            const m1f4 g = *reinterpret_cast<const m1f4*>(dyn + (long)oy * W + xq);
+#pragma unroll
+            for (int c = 0; c < M1W_CH; ++c) {
+                const bool cok = c0 + c < C;
+                const float* xc = x + ((long)n * C + (cok ? c0 + c : 0)) * hw;
+                m1_row6(xc + (long)(oy + 1) * W, xq, W, cok && oy + 1 < H, ring[c][2]);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[c][kh * 3 + kw] += g[p] * ring[c][kh][p + kw];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { ring[c][0][q] = ring[c][1][q]; ring[c][1][q] = ring[c][2][q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < M1W_CH; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float s = wave_sum(acc[c][k]);
+            if (lane == c * 9 + k && c0 + c < C) atomicAdd(dw + (long)(c0 + c) * 9 + k, s);
+        }
+}
+
 // y[N,1,H,W] = act(conv(x[N,C,H,W], w[1,C,KH,KW], stride 1, zero padding `pad` with 2*pad = K-1) + bias)
 int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int KH, int KW, int pad,
                        int act, float slope, hipStream_t stream) {
+    if (KH == 3 && KW == 3 && pad == 1 && (W & 3) == 0 && N > 0 && H > 0) {
+        const long total = (long)N * H * (W >> 2);
+        hipLaunchKernelGGL(conv_m1_fwd3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, w, bias, y, N, C, H, W, act, slope);
+        return check_launch("conv_m1_fwd3");
+    }
     const int PH = M1_TH + KH - 1, PW = M1_TW + KW - 1;
     const size_t lds = ((size_t)M1_KC * PH * PW + (size_t)M1_KC * KH * KW) * 4;
     const long blocks = (long)N * ((W + M1_TW - 1) / M1_TW) * ((H + M1_TH - 1) / M1_TH);
@@ -127,6 +241,11 @@ int launch_conv_m1_wgrad(const float* x, const float* dy, float* dw, int N, int 
                          hipStream_t st) {
     const int T = KH * KW;
     if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)C * T, st) != hipSuccess) return fail(FAOCTASR_EHIP, "memset dw failed");
+    if (KH == 3 && KW == 3 && pad == 1 && (W & 3) == 0 && N > 0 && H > 0) {
+        const long items = (long)N * ((H + M1W_ROWS - 1) / M1W_ROWS) * ((C + M1W_CH - 1) / M1W_CH);
+        hipLaunchKernelGGL(conv_m1_wgrad3_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, x, dy, dw, N, C, H, W);
+        return check_launch("conv_m1_wgrad3");
+    }
     const int CCH = 256 / T;                                           // channels per block: one thread per (channel, tap)
     const int PH = M1_TH + KH - 1, PW = M1_TW + KW - 1;
     const size_t lds = ((size_t)CCH * PH * PW + M1_TH * M1_TW) * 4;
