@@ -182,12 +182,15 @@ def test_inference_path_eval_mode(fa, O):
     close(out, unfolded.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
     m = fa.evaluate_pairs(nets["A2B"], [(a[:1].cuda(), a[1:].cuda())])
     assert set(m) == {"psnr", "ssim", "mse", "nmi"} and m["mse"] > 0
-    y1 = fa.super_resolve(nets["A2B"], a[:1].cuda()).cpu().numpy()[0, 0]
-    g1 = a[1].numpy()[0]
-    assert m["psnr"] == pytest.approx(O.skimage_psnr(y1, g1), rel=1e-6)
-    assert m["mse"] == pytest.approx(O.skimage_mse(y1, g1), rel=1e-6)
-    assert m["ssim"] == pytest.approx(O.skimage_ssim(y1, g1), rel=1e-5, abs=1e-6)
-    assert m["nmi"] == pytest.approx(O.skimage_nmi(y1, g1), rel=1e-9)
+    # the forward is not bit-reproducible (split-K atomics), and NMI's histogram reacts to single pixels: score ONE output on both sides
+    yd = fa.super_resolve(nets["A2B"], a[:1].cuda())
+    md = fa.image_metrics(yd, a[1:].cuda()).cpu().numpy()[0]
+    y1, g1 = yd.cpu().numpy()[0, 0], a[1].numpy()[0]
+    assert md[0] == pytest.approx(O.skimage_psnr(y1, g1), rel=1e-6)
+    assert md[2] == pytest.approx(O.skimage_mse(y1, g1), rel=1e-6)
+    assert md[1] == pytest.approx(O.skimage_ssim(y1, g1), rel=1e-5, abs=1e-6)
+    assert md[3] == pytest.approx(O.skimage_nmi(y1, g1), rel=1e-9)
+    assert m["psnr"] == pytest.approx(md[0], rel=1e-4) and m["ssim"] == pytest.approx(md[1], rel=1e-4) and m["nmi"] == pytest.approx(md[3], rel=1e-4)
     # LR schedule hook (train.py:105-110): linear decay to 0 after decay_epoch
     ts = fa.TrainStep(nets["A2B"], nets["B2A"], nets["D_A"], nets["D_B"])
     ts.lr_step(1.3e-4, fa.LambdaLR(50, 0, 10).step, 30)
