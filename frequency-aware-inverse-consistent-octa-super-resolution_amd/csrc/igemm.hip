@@ -617,6 +617,9 @@ int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, 
     if (IW >= 24) {
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
+        rc = launch_wgrad_s1(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,
+                             (hipStream_t)stream);
+        if (rc != 0) { set_route(ROUTE_WGRAD_S1); return rc < 0 ? rc : FAOCTASR_OK; }
         rc = launch_wgrad_patch(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,
                                 (hipStream_t)stream);
         if (rc != 0) { set_route(ROUTE_WGRAD_PATCH); return rc < 0 ? rc : FAOCTASR_OK; }

@@ -30,7 +30,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WgS1Geom {
-    int N, C, H, W;          // X and dY maps have the same extent (stride 1, pad = (K-1)/2)
+    int N, C, H, W;          // gathered tensor X (H x W per channel)
+    int OH, OW;              // dY map: H x W for stride 1 (pad = (K-1)/2), H/2 x W/2 for stride 2
     int M, KH, KW, pad, reflect;
     long wsm, wsc;           // dW element strides of row m / channel c (taps contiguous)
     int ncols;               // C * KH * KW
@@ -40,8 +41,9 @@ struct WgS1Geom {
 };
 
 constexpr int S1_LD = 68;                 // dY tile row stride in LDS (floats): 16-byte rows, conflict-free ds_read_b128 column reads
-constexpr int S1_RS = 40;                 // patch row stride: ten 4-float chunks
-constexpr int S1_NDV = 4, S1_NPV = 5;     // 16-byte pieces per thread and tile: dY, patch (at most)
+constexpr int S1_NDV = 4;                 // 16-byte dY pieces per thread and tile
+// per input stride S: patch row stride in floats (ten / eighteen 4-float chunks: columns S*x0 - 4 ... ) and patch pieces per thread
+template <int S> struct S1Cfg { static constexpr int RS = S == 1 ? 40 : 72, NCK = RS / 4, NPV = S == 1 ? 5 : 6; };
 constexpr int S1_TRASH = 16;              // bytes at the end of the LDS image that absorb the stores of unused patch pieces
 
 template <int I, int N, class F>
@@ -52,13 +54,16 @@ __device__ __forceinline__ void s1_static_for(F&& f) {
     }
 }
 
-// 256 threads = 4 waves; block tile 64 rows (m) x CT = (4 / WK) * NI * 32 columns (c,t); pixel tile 2 rows x 32.
-template <int WK, int NI>
+// 256 threads = 4 waves; block tile 64 rows (m) x CT = (4 / WK) * NI * 32 columns (c,t); pixel tile 2 rows x 32 of the dY map.
+// S = input stride: 1 (the "same" 3x3 / 7x7 layers) or 2 (4x4 stride-2 convolutions and, with the operands swapped, the 4x4
+// transposed convolution: round 1's wgrad_patch kernel keeps the shapes this one declines).
+template <int WK, int NI, int S>
 __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                           const WgS1Geom g) {
     constexpr int WN = 4 / WK, CT = WN * NI * 32, KS = 32 / WK;          // k-steps (pixel pairs) per tile and wave
     constexpr int NQ = KS / 4;                                           // quads of k-steps = dY fragment reads
     constexpr int NRD = 2 + 2 * NI;                                      // LDS read instructions per quad
+    constexpr int S1_RS = S1Cfg<S>::RS, NCK = S1Cfg<S>::NCK, S1_NPV = S1Cfg<S>::NPV;
     static_assert(NRD <= 15, "counted lgkmcnt wait");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,10 +92,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
     int c_hi = (col0 + CT - 1) / T;
     c_hi = c_hi < g.C ? c_hi : g.C - 1;
     const int NCH = c_hi - c_lo + 1;
-    const int PH = g.KH + 1;                                             // patch rows of a 2-row tile
+    const int PH = g.KH + S;                                             // patch rows of a 2-row tile
     const int CS = PH * S1_RS + 4;                                       // channel stride (floats): +4 turns 4-way bank conflicts into 2-way
     const int npatch = NCH * CS;
-    const long hw = (long)g.H * g.W;
+    const long hw = (long)g.H * g.W, ohw = (long)g.OH * g.OW;
 
     const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
     const long tile0 = (long)slice * g.tiles_per_block;
@@ -107,18 +112,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
 
     // ---- tile-invariant per-thread staging state ------------------------------------------------------------------------
     // dY piece j: rows m = (tid >> 4) + 16 j, tile row (tid >> 3) & 1, pixels 4 (tid & 7) .. +3
-    const unsigned d_goff = 4u * (unsigned)((tid >> 4) * (int)hw + ((tid >> 3) & 1) * g.W + (tid & 7) * 4);   // + j * 16 * hw floats
+    const unsigned d_goff = 4u * (unsigned)((tid >> 4) * (int)ohw + ((tid >> 3) & 1) * g.OW + (tid & 7) * 4);   // + j * 16 * ohw floats
     const unsigned d_lds = lds0 + 4u * (unsigned)((tid >> 4) * S1_LD + ((tid >> 3) & 1) * 32 + (tid & 7) * 4);   // + j * 16 * S1_LD floats
     // patch piece i: item = tid + 256 i -> (channel, row, chunk)
     unsigned p_goff[S1_NPV], p_lds[S1_NPV];
     int p_rc[S1_NPV];                                                    // row << 4 | chunk, or -1 = piece unused
-    const int items = NCH * PH * 10;
+    const int items = NCH * PH * NCK;
 #pragma unroll
     for (int i = 0; i < S1_NPV; ++i) {
         const int item = tid + 256 * i;
-        const int c = item / (PH * 10), r = item - c * (PH * 10), row = r / 10, ck = r - row * 10;
+        const int c = item / (PH * NCK), r = item - c * (PH * NCK), row = r / NCK, ck = r - row * NCK;
         const bool use = item < items;
-        p_rc[i] = use ? (row << 4) | ck : -1;
+        p_rc[i] = use ? (row << 5) | ck : -1;
         p_goff[i] = 4u * (unsigned)(c * (int)hw + row * g.W + 4 * ck);
         p_lds[i] = use ? p_lds0 + 4u * (unsigned)(c * CS + row * S1_RS + 4 * ck) : trash;
     }
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
 
     struct Tile {                                                        // uniform
         const float* dsrc;                                               // dY at (n, m0, y0, x0)
-        const float* xsrc;                                               // X at (n, c_lo, y0 - pad, x0 - 4): may lie outside the tensor, only in-range pieces are read
+        const float* xsrc;                                               // X at (n, c_lo, S*y0 - pad, S*x0 - 4): may lie outside the tensor, only in-range pieces are read
         int y0, x0;
         bool interior;
     };
@@ -143,9 +148,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
     auto next_tile = [&]() {
         Tile t;
         t.y0 = ty * 2; t.x0 = tx * 32;
-        t.dsrc = dy + ((long)tn * g.M + m0) * hw + (long)t.y0 * g.W + t.x0;
-        t.xsrc = x + ((long)tn * g.C + c_lo) * hw + (long)(t.y0 - g.pad) * g.W + (t.x0 - 4);
-        t.interior = t.y0 - g.pad >= 0 && t.y0 - g.pad + PH <= g.H && t.x0 >= 4 && t.x0 + 36 <= g.W;
+        t.dsrc = dy + ((long)tn * g.M + m0) * ohw + (long)t.y0 * g.OW + t.x0;
+        t.xsrc = x + ((long)tn * g.C + c_lo) * hw + (long)(S * t.y0 - g.pad) * g.W + (S * t.x0 - 4);
+        t.interior = S * t.y0 - g.pad >= 0 && S * t.y0 - g.pad + PH <= g.H && S * t.x0 >= 4 && S * t.x0 - 4 + S1_RS <= g.W;
         if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
         return t;
     };
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
     auto load_piece = [&](const Tile& t, auto jc) {
         constexpr int j = decltype(jc)::value;
         if constexpr (j < S1_NDV) {
-            dv[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(t.dsrc + (long)j * 16 * hw) + d_goff);
+            dv[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(t.dsrc + (long)j * 16 * ohw) + d_goff);
         } else {
             constexpr int i = j - S1_NDV;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
                 if (rc >= 0) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(t.xsrc) + p_goff[i]);
                 if (g.reflect) pflag &= ~(3 << (2 * i));
             } else if (rc >= 0) {
-                const int row = rc >> 4, ck = rc & 15;
-                const int iy = t.y0 - g.pad + row, gx = t.x0 - 4 + 4 * ck;
+                const int row = rc >> 5, ck = rc & 31;
+                const int iy = S * t.y0 - g.pad + row, gx = S * t.x0 - 4 + 4 * ck;
                 if (!g.reflect) {                                        // zero padding: rows / chunks outside the image stay zero
                     if ((unsigned)iy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
                         v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(t.xsrc) + p_goff[i]);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
         col = col < g.ncols ? col : g.ncols - 1;                         // clamped columns are never written back
         const int c = col / T, t = col - c * T;
         const int kh = t / g.KW, kw = t - kh * g.KW;
-        b_addr[ni] = p_lds0 + 4u * (unsigned)((c - c_lo) * CS + (rowsel + kh) * S1_RS + kw + (4 - g.pad) + xoff);
+        b_addr[ni] = p_lds0 + 4u * (unsigned)((c - c_lo) * CS + (rowsel * S + kh) * S1_RS + kw + (4 - g.pad) + S * xoff);
     }
 
     f32x16 acc[2][NI];
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
                 for (int ni = 0; ni < NI; ++ni) {
                     const unsigned b_ = ba[ni];                          // (asm operands cannot name a captured array element)
                     f32x2 v;
-                    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(b_), "n"(4 * q + 2 * kp), "n"(4 * q + 2 * kp + 1));
+                    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(b_), "n"(S * (4 * q + 2 * kp)), "n"(S * (4 * q + 2 * kp + 1)));
                     B[kp][ni] = v;
                 }
         };
@@ -360,14 +365,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(const float* __restric
     }
 }
 
-template <int WK, int NI>
+template <int WK, int NI, int S>
 static bool s1_fits(const WgS1Geom& g, size_t* lds_out) {
     constexpr int CT = (4 / WK) * NI * 32;
     const int T = g.KH * g.KW;
     int nch = (CT + T - 2) / T + 1;                                      // channels a slab of CT columns can touch
     nch = nch < g.C ? nch : g.C;
-    const int PH = g.KH + 1, CS = PH * S1_RS + 4;
-    if ((long)nch * PH * 10 > 256 * S1_NPV) return false;               // patch pieces per thread
+    const int PH = g.KH + S, CS = PH * S1Cfg<S>::RS + 4;
+    if ((long)nch * PH * S1Cfg<S>::NCK > 256 * S1Cfg<S>::NPV) return false;       // patch pieces per thread
     size_t lds = 2 * (size_t)64 * S1_LD * 4 + 2 * (size_t)nch * CS * 4 + S1_TRASH;
     const size_t red = WK == 2 ? (size_t)2 * 2 * NI * 16 * 64 * 4 : 0;   // epilogue exchange reuses the tile buffers
     lds = lds > red ? lds : red;
@@ -376,7 +381,7 @@ static bool s1_fits(const WgS1Geom& g, size_t* lds_out) {
     return true;
 }
 
-template <int WK, int NI>
+template <int WK, int NI, int S>
 static int s1_launch(const float* x, const float* dy, float* dw, WgS1Geom g, size_t lds, hipStream_t s) {
     constexpr int CT = (4 / WK) * NI * 32;
     g.gx = (g.ncols + CT - 1) / CT;
@@ -388,7 +393,7 @@ static int s1_launch(const float* x, const float* dy, float* dw, WgS1Geom g, siz
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    auto k = wgrad_s1_kernel<WK, NI>;
+    auto k = wgrad_s1_kernel<WK, NI, S>;
     lds_optin((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(256), lds, s, x, dy, dw, g);
     return check_launch("wgrad_s1");
@@ -398,17 +403,27 @@ static int s1_launch(const float* x, const float* dy, float* dw, WgS1Geom g, siz
 // zeroed / hold the running gradient (accumulation is by atomics).
 int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
-    if (stride != 1 || OH != IH || OW != IW || KH != KW || 2 * pad != KH - 1) return 0;              // "same" convolutions only
-    if ((M & 63) || (OW & 31) || (OH & 1) || pad < 1 || pad > 3 || KW + 31 + (4 - pad) > S1_RS || C * KH * KW < 192) return 0;
+    if (KH != KW || (M & 63) || (OW & 31) || (OH & 1) || C * KH * KW < 128) return 0;
     if ((long)C * IH * IW >= (1L << 29)) return 0;                       // 32-bit byte offsets inside one image
     WgS1Geom g;
-    g.N = N; g.C = C; g.H = IH; g.W = IW; g.M = M; g.KH = KH; g.KW = KW; g.pad = pad; g.reflect = reflect;
+    g.N = N; g.C = C; g.H = IH; g.W = IW; g.OH = OH; g.OW = OW; g.M = M; g.KH = KH; g.KW = KW; g.pad = pad; g.reflect = reflect;
     g.wsm = wsm; g.wsc = wsc; g.ncols = C * KH * KW;
     g.tiles_x = OW / 32; g.tiles_y = OH / 2;
     g.tiles_per_block = 1; g.gx = g.gy = g.slices = 1;
+    if (stride == 2) {
+        // 4x4 stride-2 pad-1 layers (discriminator convolutions, and the generator's 4x4 transposed convolution with x / dy swapped):
+        // patch column of output x at tap kw = 2 x + kw - pad + 4 <= 62 + KW + 3 - pad < 72; zero padding only
+        if (reflect || pad != 1 || KH != 4 || IH != 2 * OH || IW != 2 * OW || (IW & 3)) return 0;
+        size_t l = 0;
+        if (!s1_fits<2, 2, 2>(g, &l)) return 0;
+        const int rc = s1_launch<2, 2, 2>(x, dy, dw, g, l, s);
+        return rc == FAOCTASR_OK ? 1 : rc;
+    }
+    if (stride != 1 || OH != IH || OW != IW || 2 * pad != KH - 1) return 0;                            // "same" convolutions only
+    if (pad < 1 || pad > 3 || KW + 31 + (4 - pad) > S1Cfg<1>::RS || C * KH * KW < 192) return 0;
     // slab width: least padded MFMA work; ties go to the wider register tile per wave (fewer LDS reads per MFMA)
     size_t l23 = 0, l12 = 0, l13 = 0;
-    const bool f23 = s1_fits<2, 3>(g, &l23), f12 = s1_fits<1, 2>(g, &l12), f13 = s1_fits<1, 3>(g, &l13);
+    const bool f23 = s1_fits<2, 3, 1>(g, &l23), f12 = s1_fits<1, 2, 1>(g, &l12), f13 = s1_fits<1, 3, 1>(g, &l13);
     auto padded = [&](int ct) { return (long)((g.ncols + ct - 1) / ct) * ct; };
     long best = -1;
     int pick = 0;
@@ -422,9 +437,9 @@ int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, in
     if (f12 && (best < 0 || padded(256) < best)) { best = padded(256); pick = 12; }
 #endif
     int rc;
-    if (pick == 23) rc = s1_launch<2, 3>(x, dy, dw, g, l23, s);
-    else if (pick == 12) rc = s1_launch<1, 2>(x, dy, dw, g, l12, s);
-    else if (pick == 13) rc = s1_launch<1, 3>(x, dy, dw, g, l13, s);
+    if (pick == 23) rc = s1_launch<2, 3, 1>(x, dy, dw, g, l23, s);
+    else if (pick == 12) rc = s1_launch<1, 2, 1>(x, dy, dw, g, l12, s);
+    else if (pick == 13) rc = s1_launch<1, 3, 1>(x, dy, dw, g, l13, s);
     else return 0;
     return rc == FAOCTASR_OK ? 1 : rc;
 }

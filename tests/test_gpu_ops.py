@@ -78,6 +78,9 @@ CONV_CASES = [
     (2, 16, 32, 64, 128, 5, 1, 2, False, True, None),         # 5x5 pad 2, two row blocks
     (5, 24, 8, 64, 64, 3, 1, 1, False, False, None),          # 216 columns: a second, mostly empty slab; odd batch
     (3, 128, 10, 96, 128, 3, 1, 1, False, False, None),       # two 64-channel slabs x two row blocks (bf16x3 weight gradient: wgrad_x3.hip)
+    # stride-2 4x4 weight gradient through wgrad_s1.hip (S = 2): output map 32 / 64 / 96 wide, top / bottom / left / right borders
+    (2, 16, 12, 64, 64, 4, 2, 1, False, True, None),          # one tile column, 3 tile rows (6 output rows)
+    (2, 24, 64, 192, 128, 4, 2, 1, False, False, None),       # 3 tile columns (border, interior, border), two row blocks, 384 columns
 ]
 
 
@@ -131,6 +134,7 @@ CONVT_CASES = [
     (1, 20, 25, 31, 12, 3, 2, 1, 1, True),        # ragged
     (2, 16, 40, 40, 8, 3, 1, 1, 0, True),         # stride 1 transposed
     (2, 8, 30, 30, 6, 4, 2, 1, 0, True),
+    (2, 64, 16, 32, 16, 4, 2, 1, 0, False),       # 4x4 s2 transposed conv whose weight gradient takes wgrad_s1.hip (S = 2, operands swapped)
 ]
 
 
