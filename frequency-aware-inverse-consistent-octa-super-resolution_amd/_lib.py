@@ -17,6 +17,8 @@ _SIG = {
     "last_error": (ctypes.c_char_p, ""),
     "last_route": (_I, ""),
     "conv_wpack_floats": (_L, "iiiiiiii"),
+    "conv_pack_job": (_L, "p l i pp iiiiiiiii i i i"),
+    "conv_pack_run": (_I, "p i l p"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
     "conv2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),
@@ -67,6 +69,7 @@ _SIG = {
     "param_broadcast": (_I, "p l i p p"),
 }
 _CODE = {"p": _P, "i": _I, "l": _L, "f": _F}
+PACK_JOB_BYTES = 1024          # include/faoctasr.h FAOCTASR_PACK_JOB_BYTES
 
 _lib = None
 

@@ -1,0 +1,46 @@
+// Batched weight packing: every packed-weight image of a train step in ONE launch.
+//
+// A step packs ~240 weight images (forward + input-gradient image of every convolution, once per optimizer update).  As
+// separate launches they cost ~10 us each -- 2.6 ms per step at batch 8, almost all of it launch latency of tiny dependent
+// kernels.  faoctasr_conv_pack_job records, per layer, exactly the job the per-layer path would launch (same geometry, same
+// element loop: pack_bodies.h); the caller keeps the job table in device memory and faoctasr_conv_pack_run packs all of them
+// with one grid: block -> job by binary search over the jobs' first-block prefix, then the job's own grid-stride loop.
+#include <cstring>
+
+#include "common.h"
+#include "igemm_geom.h"
+#include "pack_bodies.h"
+
+namespace faoctasr {
+
+__global__ __launch_bounds__(256) void conv_pack_batch_kernel(const char* __restrict__ jobs, int njobs) {
+    const long b = blockIdx.x;
+    int lo = 0, hi = njobs - 1;                    // last job with block0 <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (reinterpret_cast<const PackJob*>(jobs + (size_t)mid * PACK_JOB_BYTES)->block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackJob& J = *reinterpret_cast<const PackJob*>(jobs + (size_t)lo * PACK_JOB_BYTES);
+    const long lb = b - J.block0;
+    if (lb >= J.blocks) return;                    // cannot happen for a table built by faoctasr_conv_pack_job; keeps a bad table harmless
+    const long first = lb * 256 + threadIdx.x, stride = (long)J.blocks * 256;
+    if (J.type == PACK_PATCH) patch_pack_elems(J.w, J.wp, J.g.patch, J.total, first, stride);
+    else if (J.type == PACK_WINO) wino_pack_elems(J.w, J.wp, J.g.wino, J.total, first, stride);
+    else if (J.type == PACK_SPLIT) split_pack_elems(J.w, reinterpret_cast<__bf16*>(J.wp), J.g.split, J.total, first, stride);
+}
+
+}  // namespace faoctasr
+
+using namespace faoctasr;
+
+extern "C" {
+
+int faoctasr_conv_pack_run(const void* jobs_dev, int njobs, long nblocks, faoctasr_stream_t stream) {
+    if (njobs == 0 || nblocks == 0) return FAOCTASR_OK;
+    if (!jobs_dev || njobs < 0 || nblocks < 0 || nblocks > 0x7fffffffL) return fail(FAOCTASR_EINVAL, "conv_pack_run: bad job table");
+    hipLaunchKernelGGL(conv_pack_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const char*)jobs_dev, njobs);
+    return check_launch("conv_pack_batch");
+}
+
+}  // extern "C"

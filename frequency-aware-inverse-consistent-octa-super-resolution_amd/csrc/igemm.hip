@@ -13,6 +13,8 @@
 // 412-414,438 (3x3 @64ch), 431/469 (ConvTranspose2d), 450-451,472-473 (ReflectionPad2d(3)+7x7),
 // 458 (3x3 s2), 494,499 (3x3 @256ch); backward = aten::convolution_backward under
 // loss.backward() (train.py:238,255,267).
+#include <cstring>
+
 #include "common.h"
 #include "igemm_geom.h"
 
@@ -449,21 +451,30 @@ static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || 
 // wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
 // precision: 0 = f32 MFMA, Winograd F(2x2,3x3) for the dense stride-1 3x3 gathers and direct implicit GEMM elsewhere;
 //            1 = f32 MFMA, direct implicit GEMM only; 2 = bf16x3 split operands on the bf16 MFMA where the layer shape allows it
+// sink: record the weight-packing job this call would launch (wpack_state 1) and launch nothing (faoctasr_conv_pack_job);
+// sink->blocks stays 0 when the call's route uses no packed image.
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
-                      int wpack_state, int precision, hipStream_t s) {
+                      int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr) {
     if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     if (wpack && wpack_state && precision == 2) {
-        const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
+        const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
+        if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total); return FAOCTASR_OK; }
         if (rc != 0) { set_route(ROUTE_BF16X3); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state && precision == 0) {
-        const int rc = wino_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s);
+        const int rc = wino_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
+        if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total); return FAOCTASR_OK; }
         if (rc != 0) { set_route(ROUTE_WINOGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state) {
         PatchGeom pg;
         int rc = patch_geom_from(g, pg);
         if (rc) return rc;
+        if (sink) {
+            sink->type = PACK_PATCH; sink->w = w; sink->wp = wpack; sink->g.patch = pg; sink->total = pg.pack_off[4];
+            sink->blocks = pack_job_blocks(sink->total);
+            return FAOCTASR_OK;
+        }
         if (wpack_state == 1) {
             rc = launch_pack(w, wpack, pg, s);
             if (rc) return rc;
@@ -513,6 +524,48 @@ long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stri
     }
     if (rc) return rc;
     return wpack_floats(g, precision);
+}
+
+// The packing job a wpack_state == 1 call of the matching entry point would launch, written to a host slot of
+// FAOCTASR_PACK_JOB_BYTES; (N, C, IH, IW, M, ...) exactly as that call receives them.  Returns the job's blocks (0: the call's
+// route has no packed image, the slot is then unused), which the caller accumulates into the next job's block_base.
+long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const float* w, float* wpack, int N, int C, int IH, int IW, int M,
+                            int KH, int KW, int stride, int pad, int reflect, int out_pad, int precision) {
+    if (!job_host || !w || !wpack) return fail(FAOCTASR_EINVAL, "conv_pack_job: null pointer");
+    if (N <= 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0 || block_base < 0) return fail(FAOCTASR_EINVAL, "conv_pack_job: bad shape");
+    IgemmGeom g;
+    const long kk = (long)KH * KW;
+    int rc, OH, OW;
+    switch (kind) {
+        case 0:
+            OH = (IH + 2 * pad - KH) / stride + 1; OW = (IW + 2 * pad - KW) / stride + 1;
+            if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32) return 0;   // VALU head
+            rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * kk, kk);
+            break;
+        case 1:
+            OH = (IH + 2 * pad - KH) / stride + 1; OW = (IW + 2 * pad - KW) / stride + 1;
+            rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, kk, (long)C * kk);
+            break;
+        case 2:
+            OH = (IH - 1) * stride - 2 * pad + KH + out_pad; OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
+            rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, kk, (long)M * kk);
+            break;
+        case 3:
+            OH = (IH - 1) * stride - 2 * pad + KH + out_pad; OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
+            rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * kk, kk);
+            break;
+        default: return fail(FAOCTASR_EINVAL, "conv_pack_job: unknown kind %d", kind);
+    }
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_pack_job: bad shape");
+    if (rc) return rc;
+    PackJob job{};
+    rc = run_gather(nullptr, w, nullptr, nullptr, g, FAOCTASR_ACT_NONE, 0.f, wpack, 1, precision, nullptr, &job);
+    if (rc) return rc;
+    if (job.blocks <= 0 || job.total <= 0) return 0;
+    job.block0 = block_base;
+    memset(job_host, 0, PACK_JOB_BYTES);
+    memcpy(job_host, &job, sizeof(job));
+    return job.blocks;
 }
 
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,

@@ -18,6 +18,7 @@
 //     pipelined with hand-counted waits.
 #include "common.h"
 #include "igemm_geom.h"
+#include "pack_bodies.h"
 #include <cstdlib>
 
 namespace faoctasr {
@@ -27,18 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SP_MT = 64;         // output channels per block
 constexpr int SP_NPI = 6;         // (pixel, h) items staged per thread
-
-struct SplitGeom {
-    int N, C, IH, IW, M, OH, OW, SI, SO, nphase, reflect, act;
-    float slope;
-    int Mpad;
-    long wsm, wsc;
-    int py[4], px[4], gh[4], gw[4], t0[5], oy0[4], ox0[4], span_y[4], span_x[4];
-    int tg[4];                     // taps per tap group
-    long pack_off[5];              // bf16 element offset of each phase inside a plane
-    long plane_stride;             // bf16 elements between the hi and the lo plane
-    int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
-};
 
 __device__ __forceinline__ int reflect_idx_s(int i, int n) {
     i = i < 0 ? -i : i;
@@ -65,24 +54,7 @@ __device__ __forceinline__ void wait_keep_next(bf16x8 (&a)[MI][2], bf16x8 (&b)[N
 // weight packing: fp32 W (arbitrary m / c strides, tap list) -> two bf16 planes in the LDS image order
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom g, long total) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int ph = 0;
-        while (ph + 1 < g.nphase && i >= g.pack_off[ph + 1]) ++ph;
-        long li = i - g.pack_off[ph];
-        const int T = g.t0[ph + 1] - g.t0[ph];
-        const int j = (int)(li & 7); li >>= 3;
-        const int m = (int)(li % g.Mpad); li /= g.Mpad;
-        const int h = (int)(li & 1); li >>= 1;
-        const int t = (int)(li % T);
-        const int g16 = (int)(li / T);
-        const int c = g16 * 16 + 8 * h + j;
-        float v = 0.f;
-        if (m < g.M && c < g.C) v = w[(long)m * g.wsm + (long)c * g.wsc + (g.taps[g.t0[ph] + t] >> 16)];
-        const __bf16 hi = (__bf16)v;
-        wp[i] = hi;
-        wp[g.plane_stride + i] = (__bf16)(v - (float)hi);
-    }
+    split_pack_elems(w, wp, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -515,9 +487,13 @@ int launch_split(const float* x, const float* wp, const float* bias, float* y, S
 }
 
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s) {
+              int wpack_state, hipStream_t s, PackJob* sink) {
     SplitGeom g;
     if (!split_geom_from(f, g)) return 0;
+    if (sink) {
+        sink->type = PACK_SPLIT; sink->w = w; sink->wp = wpack; sink->g.split = g; sink->total = g.pack_off[4];
+        return 1;
+    }
     if (wpack_state == 1) {
         const int rc = launch_split_pack(w, wpack, g, s);
         if (rc) return rc;

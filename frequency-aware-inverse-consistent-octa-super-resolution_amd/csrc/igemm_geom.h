@@ -31,6 +31,53 @@ struct PatchGeom {
     int taps[64];
 };
 
+// Winograd F(2x2,3x3) kernel (igemm_wino.hip)
+constexpr int WN_MT = 64;                 // output channels per block
+constexpr int WN_KC = 8;                  // channels per chunk
+struct WinoGeom {
+    int N, C, IH, IW, M, OH, OW, act;
+    float slope;
+    int oy0, ox0;                  // input offset of filter tap (0, 0) relative to the output pixel
+    int widx[9];                   // weight index of filter tap (i, j)
+    long wsm, wsc;
+    int nchunks, mtiles;
+};
+
+// bf16x3 split-precision gather kernel (igemm_bf16x3.hip)
+struct SplitGeom {
+    int N, C, IH, IW, M, OH, OW, SI, SO, nphase, reflect, act;
+    float slope;
+    int Mpad;
+    long wsm, wsc;
+    int py[4], px[4], gh[4], gw[4], t0[5], oy0[4], ox0[4], span_y[4], span_x[4];
+    int tg[4];                     // taps per tap group
+    long pack_off[5];              // bf16 element offset of each phase inside a plane
+    long plane_stride;             // bf16 elements between the hi and the lo plane
+    int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
+};
+
+// One weight-packing job of a batched launch (conv_pack.hip; include/faoctasr.h FAOCTASR_PACK_JOB_BYTES).  A job is what a
+// wpack_state == 1 call would have launched by itself: the same geometry, the same element order.
+enum PackType { PACK_PATCH = 0, PACK_WINO = 1, PACK_SPLIT = 2 };
+struct PackJob {
+    long block0;                   // first block of this job in the batched grid
+    long total;                    // packed elements
+    const float* w;
+    float* wp;
+    int type, blocks;
+    union {
+        PatchGeom patch;
+        WinoGeom wino;
+        SplitGeom split;
+    } g;
+};
+constexpr int PACK_JOB_BYTES = 1024;
+static_assert(sizeof(PackJob) <= PACK_JOB_BYTES, "PackJob outgrew its slot");
+inline int pack_job_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 1024 ? 1024 : b);
+}
+
 int patch_geom_from(const IgemmGeom& f, PatchGeom& g);
 long patch_pack_floats(const PatchGeom& g);
 int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s);
@@ -47,14 +94,14 @@ int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, in
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 
 // bf16x3 split-precision gather kernel (igemm_bf16x3.hip)
-struct SplitGeom;
+// `sink` (wpack_state == 1 only): record the packing job there instead of launching anything -- 1 recorded, 0 not eligible
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s);          // 1 launched, 0 not eligible, <0 error
+              int wpack_state, hipStream_t s, PackJob* sink = nullptr);          // 1 launched, 0 not eligible, <0 error
 long split_pack_floats_for(const IgemmGeom& f);       // 0 when not eligible
 
 // Winograd F(2x2,3x3) fp32 kernel for dense stride-1 3x3 gathers (igemm_wino.hip)
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-             int wpack_state, hipStream_t s);           // 1 launched, 0 not eligible, <0 error
+             int wpack_state, hipStream_t s, PackJob* sink = nullptr);           // 1 launched, 0 not eligible, <0 error
 long wino_pack_floats_for(const IgemmGeom& f);        // 0 when not eligible
 
 // single-output-channel 'same' stride-1 convolution on the VALU (conv_m1.hip)

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "igemm_geom.h"
+#include "pack_bodies.h"
 
 namespace faoctasr {
 
@@ -75,23 +76,9 @@ __device__ __forceinline__ void wait_frags_all(float (&a)[MI], float (&b)[NI]) {
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(b[0]));
 }
 
-// pack kernel: one thread per packed element
+// pack kernel: one thread per packed element (pack_bodies.h)
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, const PatchGeom g, long total) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int ph = 0;
-        while (ph + 1 < g.nphase && i >= g.pack_off[ph + 1]) ++ph;
-        const long li = i - g.pack_off[ph];
-        const int T = g.t0[ph + 1] - g.t0[ph], KC = g.kc[ph];
-        const int m = (int)(li % g.Mpad);
-        const long row = li / g.Mpad;                 // chunk * (KC*T) + t*KC + c
-        const int chunk = (int)(row / (KC * T));
-        const int r = (int)(row - (long)chunk * KC * T);
-        const int t = r / KC, c = chunk * KC + (r - t * KC);
-        float v = 0.f;
-        if (m < g.M && c < g.C) v = w[(long)m * g.wsm + (long)c * g.wsc + (g.taps[g.t0[ph] + t] >> 16)];
-        wp[i] = v;
-    }
+    patch_pack_elems(w, wp, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 template <int WM, int WN, int MI, int NI, int SI, int DENSE = 0, int KCS = 2>

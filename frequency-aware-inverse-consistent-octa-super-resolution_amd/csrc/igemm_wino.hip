@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "igemm_geom.h"
+#include "pack_bodies.h"
 
 #ifndef WINO_TRACE
 #define WINO_TRACE 0       // diagnostics (tools/variants.py + tools/wino_trace.py): block 0 stamps s_memtime of its phases
@@ -53,20 +54,9 @@ namespace faoctasr {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
-constexpr int WN_MT = 64;                 // output channels per block
-constexpr int WN_KC = 8;                  // channels per chunk
 constexpr int WN_U_FLOATS = 16 * WN_KC * WN_MT;      // 8192 floats = 32 KiB per chunk
 constexpr int WN_V_FLOATS = 16 * WN_KC * 32;         // 4096 floats = 16 KiB per chunk
 constexpr unsigned WN_SENT = 0x40000000u;            // offset sentinel: beyond any admitted per-image extent
-
-struct WinoGeom {
-    int N, C, IH, IW, M, OH, OW, act;
-    float slope;
-    int oy0, ox0;                  // input offset of filter tap (0, 0) relative to the output pixel
-    int widx[9];                   // weight index of filter tap (i, j)
-    long wsm, wsc;
-    int nchunks, mtiles;
-};
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -76,37 +66,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// U = G g G^T, written in the order the kernel's LDS-DMA wants: [mtile][chunk][xi][k][m][j], c = chunk*8 + k + 4j
+// U = G g G^T, written in the order the kernel's weight waves want: [mtile][chunk][xi][k][m][j], c = chunk*8 + k + 4j (pack_bodies.h)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, const WinoGeom g, long total) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        long li = i;
-        const int j = (int)(li & 1); li >>= 1;
-        const int ml = (int)(li & 63); li >>= 6;
-        const int k = (int)(li & 3); li >>= 2;
-        const int xi = (int)(li & 15); li >>= 4;
-        const int ch = (int)(li % g.nchunks);
-        const int mt = (int)(li / g.nchunks);
-        const int m = mt * WN_MT + (ml ^ (16 * (k & 1))), c = ch * WN_KC + k + 4 * j;      // slot ml holds row ml ^ 16 (k & 1)
-        float v = 0.f;
-        if (m < g.M && c < g.C) {
-            const float* wp = w + (long)m * g.wsm + (long)c * g.wsc;
-            float gg[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) gg[a][b] = wp[g.widx[a * 3 + b]];
-            const int a = xi >> 2, b = xi & 3;
-            // row a of G applied to the columns, then row b of G applied to the result
-            float t[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                t[q] = a == 0 ? gg[0][q] : a == 3 ? gg[2][q] : a == 1 ? 0.5f * (gg[0][q] + gg[1][q] + gg[2][q]) : 0.5f * (gg[0][q] - gg[1][q] + gg[2][q]);
-            }
-            v = b == 0 ? t[0] : b == 3 ? t[2] : b == 1 ? 0.5f * (t[0] + t[1] + t[2]) : 0.5f * (t[0] - t[1] + t[2]);
-        }
-        up[i] = v;
-    }
+    wino_pack_elems(w, up, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict__ x, const float* __restrict__ up,
@@ -534,10 +496,15 @@ long wino_pack_floats_for(const IgemmGeom& f) {
 }
 
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-             int wpack_state, hipStream_t s) {
+             int wpack_state, hipStream_t s, PackJob* sink) {
     WinoGeom g;
     if (!wino_geom_from(f, g) || !wino_worth(g)) return 0;
     g.act = act; g.slope = slope;
+    if (sink) {
+        sink->type = PACK_WINO; sink->w = w; sink->wp = wpack; sink->g.wino = g;
+        sink->total = (long)g.mtiles * g.nchunks * WN_U_FLOATS;
+        return 1;
+    }
     if (wpack_state == 1) {
         const long total = (long)g.mtiles * g.nchunks * WN_U_FLOATS;
         long blocks = (total + 255) / 256;

@@ -17,8 +17,7 @@ from ._lib import call, ptr, stream_ptr
 def folded_conv_params(conv, bn):
     """(weight, bias) of ``conv`` with the eval-mode BatchNorm ``bn`` folded in (``faoctasr_bn_fold``): what `model.eval()`
     (utils.py:186) turns conv -> BN into.  Cached on the conv module until its weights or the BN's statistics change."""
-    key = (conv.weight._version, conv.weight.data_ptr(), ops.weight_epoch, bn.weight._version, bn._stat_epoch,
-           None if conv.bias is None else conv.bias._version)
+    key = (ops._ver(conv.weight), ops._ver(bn.weight), ops._ver(bn.bias), bn._stat_epoch, None if conv.bias is None else ops._ver(conv.bias))
     hit = getattr(conv, "_folded", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]

@@ -6,6 +6,7 @@ every arithmetic kernel is ours.  Weight / affine gradients are accumulated by t
 straight into ``param.grad`` when that already exists (the flat gradient arena of
 train.TrainStep), so no per-parameter add kernels run and the all-reduce sees one buffer.
 """
+import ctypes
 import math
 
 import torch
@@ -36,7 +37,8 @@ def _c(t):
 # ----------------------------------------------------------------------------------------
 import weakref
 
-#: bumped whenever weights change behind autograd's back (ParamArena.step updates them through raw pointers)
+#: bumped whenever weights change behind autograd's back and nobody knows which (``invalidate_weight_cache``); a ``ParamArena``
+#: bumps only its own parameters' epoch cell (``p._fa_epoch``), so a generator update leaves the discriminators' images valid
 weight_epoch = 0
 use_wpack = True
 #: convolution arithmetic: 0 = fp32 MFMA with Winograd F(2x2,3x3) on the stride-1 3x3 layers (default), 1 = fp32 MFMA direct only,
@@ -44,6 +46,8 @@ use_wpack = True
 conv_precision = 0
 PRECISIONS = {"f32": 0, "f32_direct": 1, "bf16x3": 2}
 _wpack_cache = {}
+#: calls that had to pack inside the convolution call itself (state 1); a ``PackPlan`` owner watches it to learn about new images
+pack_misses = 0
 
 
 def invalidate_weight_cache():
@@ -51,25 +55,83 @@ def invalidate_weight_cache():
     weight_epoch += 1
 
 
-def _wpack(w, kind, C, M, KH, KW, stride, pad, size=None):
-    """(buffer, state) for the C ABI: state 1 = pack now, 2 = buffer already holds these weights."""
+class _PackEntry:
+    """One packed-weight image: the buffer, the gather call it belongs to (exactly the C call's arguments) and the weight
+    version it holds."""
+    __slots__ = ("wref", "buf", "ver", "kind", "dims", "reflect", "out_pad", "precision", "touched")
+
+
+def _ver(w):
+    cell = getattr(w, "_fa_epoch", None)
+    return (w._version, weight_epoch, 0 if cell is None else cell[0], w.data_ptr(), tuple(w.shape))
+
+
+def _wpack(w, kind, dims, reflect=0, out_pad=0):
+    """(buffer, state) for the C ABI: state 1 = pack now, 2 = buffer already holds these weights.  ``dims`` =
+    (N, C, IH, IW, M, KH, KW, stride, pad) exactly as the gather call ``kind`` receives them."""
+    global pack_misses
     if not use_wpack:
         return None, 0
-    key = (id(w), kind, stride, pad, conv_precision, size)
-    ver = (w._version, weight_epoch, w.data_ptr(), tuple(w.shape))
+    key = (id(w), kind, conv_precision, dims, reflect, out_pad)
     ent = _wpack_cache.get(key)
-    if ent is None or ent[0]() is not w:
+    if ent is None or ent.wref() is not w:
         if len(_wpack_cache) > 4096:
-            for k in [k for k, v in _wpack_cache.items() if v[0]() is None]:
+            for k in [k for k, v in _wpack_cache.items() if v.wref() is None]:
                 del _wpack_cache[k]
+        N, C, IH, IW, M, KH, KW, stride, pad = dims
         n = _lib.load().faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad, conv_precision)
         if n <= 0:
             return None, 0
-        ent = [weakref.ref(w), torch.empty(n, dtype=torch.float32, device=w.device), None]
+        ent = _PackEntry()
+        ent.wref, ent.buf, ent.ver = weakref.ref(w), torch.empty(n, dtype=torch.float32, device=w.device), None
+        ent.kind, ent.dims, ent.reflect, ent.out_pad, ent.precision = kind, dims, int(bool(reflect)), out_pad, conv_precision
         _wpack_cache[key] = ent
-    state = 2 if ent[2] == ver else 1
-    ent[2] = ver
-    return ent[1], state
+    ver = _ver(w)
+    ent.touched = True
+    if ent.ver == ver:
+        return ent.buf, 2
+    ent.ver = ver
+    pack_misses += 1
+    return ent.buf, 1
+
+
+class PackPlan:
+    """Every packed-weight image of a set of parameters in one launch (``faoctasr_conv_pack_job`` / ``faoctasr_conv_pack_run``,
+    csrc/conv_pack.hip): the images the last step used (``touched``) at ``precision``, for weights in ``params``.  ``run()``
+    packs them all and marks them current, so the convolution calls that follow pass ``wpack_state`` 2."""
+
+    def __init__(self, params, precision):
+        lib = _lib.load()
+        ids = {id(p) for p in params}
+        slot = ctypes.create_string_buffer(_lib.PACK_JOB_BYTES)
+        blobs, base, self.entries, device = [], 0, [], None
+        for key, e in list(_wpack_cache.items()):
+            w = e.wref()
+            if w is None or id(w) not in ids or e.precision != precision or not e.touched:
+                continue
+            e.touched = False
+            n = lib.faoctasr_conv_pack_job(slot, base, e.kind, w.data_ptr(), e.buf.data_ptr(), *e.dims, e.reflect, e.out_pad, e.precision)
+            if n < 0:
+                raise _lib.KernelError("conv_pack_job: " + lib.faoctasr_last_error().decode())
+            self.entries.append((e, w.data_ptr()))     # n == 0: the call never reads its image (64->1 head): nothing to pack, still "current"
+            if n > 0:
+                blobs.append(slot.raw)
+                base += n
+                device = w.device
+        self.njobs, self.nblocks = len(blobs), base
+        self.table = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.float32).to(device) if blobs else None   # raw bytes, carried as fp32
+
+    def run(self):
+        """False (nothing launched) when a weight has moved or died since the jobs were recorded: the owner drops the plan."""
+        live = [(e, e.wref()) for e, _ in self.entries]
+        if any(w is None or w.data_ptr() != p for (e, w), (_, p) in zip(live, self.entries)):
+            return False
+        if self.njobs:
+            call("conv_pack_run", ptr(self.table), self.njobs, self.nblocks, stream_ptr())
+        for e, w in live:
+            e.ver = _ver(w)
+            e.touched = True
+        return True
 
 
 def _grad_target(p):
@@ -95,7 +157,7 @@ class _Conv2d(Function):
             raise RuntimeError("Calculated padded input size per channel: (%d x %d). Kernel size: (%d x %d). "
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 0, C, M, KH, KW, stride, pad, (N, IH, IW))
+        wp, wst = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
              conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
@@ -119,14 +181,14 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, 0, (N, IH, IW))
+                wp, wst = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
                      conv_precision, st)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
             else:
                 dx = torch.empty_like(x)
-                wp, wst = _wpack(ctx.w_ref, 1, C, M, KH, KW, stride, pad, (N, IH, IW))
+                wp, wst = _wpack(ctx.w_ref, 1, (N, C, IH, IW, M, KH, KW, stride, pad))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
@@ -157,7 +219,7 @@ class _ConvTranspose2d(Function):
             raise _lib.KernelError("conv_transpose2d: input has %d channels, weight expects %d" % (C, Cw))
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 2, C, M, KH, KW, stride, pad, (N, IH, IW))
+        wp, wst = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
              ptr(wp), wst, conv_precision, stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
@@ -180,7 +242,7 @@ class _ConvTranspose2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wp, wst = _wpack(ctx.w_ref, 3, C, M, KH, KW, stride, pad, (N, IH, IW))
+            wp, wst = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
             call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
                  conv_precision, st)
         if ctx.needs_input_grad[1]:

@@ -102,6 +102,9 @@ class ParamArena:
                 p.data = self.flat[o:o + p.numel()].view(p.shape)
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
         self.step_count = 0
+        self._epoch = [0]                 # ops._ver: bumped by step(), which changes these parameters through raw pointers
+        for p in self.params:
+            p._fa_epoch = self._epoch
 
     def zero_grad(self):
         self.grad.zero_()
@@ -126,7 +129,7 @@ class ParamArena:
                  self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream_ptr())
         else:
             call("adamw_step_dev", ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel, ptr(hyper), stream_ptr())
-        ops.invalidate_weight_cache()      # the kernel changed the weights through raw pointers: packed images are stale
+        self._epoch[0] += 1                # the kernel changed these weights through raw pointers: their packed images are stale
 
     def hyper_values(self, step, grad_scale=1.0):
         """The 8 scalars of ``faoctasr_adamw_step_dev`` for optimizer step ``step`` (>= 1), rounded exactly as ``faoctasr_adamw_step``
@@ -168,6 +171,7 @@ class TrainStep:
         self._targets = {}
         self.device = dev
         self.comm = None
+        self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
         if self.distributed:
             if dev.type != "cuda":
                 raise KernelError("TrainStep(distributed=True) needs a GPU: the exchange is RCCL behind the C ABI")
@@ -246,6 +250,9 @@ class TrainStep:
         B = real_A.shape[0]
         ones, zeros = self.targets(B)
         ops.conv_precision = ops.PRECISIONS[self.precision]
+        misses = ops.pack_misses
+        if self._pack_plan is not None and not self._pack_plan.run():     # every packed-weight image of the step in one launch
+            self._pack_plan = None
         o = self.forward_generators(real_A, real_B)
         # (2) generators, train.py:218-239
         set_requires_grad([self.netD_A, self.netD_B], False)
@@ -267,6 +274,9 @@ class TrainStep:
         if self.distributed:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
+        if ops.pack_misses != misses and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # some convolution packed its own weights: first step, new batch size or precision -> (re)collect the images this step used
+            self._pack_plan = ops.PackPlan(self.opt_G.params + self.opt_D.params, ops.conv_precision)
         ops.conv_precision = 0
         out = {k: v.detach() for k, v in L.items()}
         if sync:

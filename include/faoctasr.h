@@ -51,6 +51,20 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
  * C >= 16, width >= 24 -- other shapes silently use the fp32 kernels).  The packed image depends on `precision` and on
  * whether the map is wide enough for the split kernel, so keep one buffer per (weights, precision, input size).  */
 long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad, int precision);
+/* Batched packing: all packed-weight images of a step in ONE launch (csrc/conv_pack.hip).  Each convolution call of
+ * train.py:166-269 re-reads weights the optimizer has just changed (train.py:239,268), i.e. ~240 images per step;
+ * packed one by one they are ~240 tiny dependent launches.  faoctasr_conv_pack_job writes, into a HOST slot of
+ * FAOCTASR_PACK_JOB_BYTES, the job that the gather call `kind` (0 conv2d_fwd, 1 conv2d_dgrad, 2 conv_transpose2d_fwd,
+ * 3 conv_transpose2d_dgrad) with exactly these arguments and wpack_state 1 would launch; it returns the job's block
+ * count (0: that call uses no packed image -- skip the slot; < 0: error).  `block_base` is the sum of the block counts
+ * of the jobs before it.  The caller copies the slots, contiguous, to device memory once and calls
+ * faoctasr_conv_pack_run(table, njobs, total_blocks, stream) after every weight update; the matching gather calls then
+ * pass wpack_state 2.  `w` / `wpack` addresses are baked into the job.                                              */
+#define FAOCTASR_PACK_JOB_BYTES 1024
+long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const float* w, float* wpack,
+                            int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                            int reflect, int out_pad, int precision);
+int faoctasr_conv_pack_run(const void* jobs_dev, int njobs, long nblocks, faoctasr_stream_t stream);
 /* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
  * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with
  * faoctasr_reflect_pad_bwd).                                                              */

@@ -651,3 +651,73 @@ def test_eval_metrics_vs_oracle_and_closed_forms(fa, O):
     assert m[3] == pytest.approx(1.0, abs=1e-12)                                  # two constant images
     m = fa.image_metrics(dev(a), dev(torch.full_like(a, 0.25))).cpu().numpy()
     assert np.allclose(m[:, 3], 1.0, atol=1e-12)                                  # H(const) = 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_batched_weight_pack_equals_per_layer_pack(fa, precision):
+    """faoctasr_conv_pack_job / faoctasr_conv_pack_run (csrc/conv_pack.hip): one launch writes, bit for bit, the packed-weight
+    images that the gather calls write themselves with wpack_state 1 -- for every route that keeps an image (LDS-patch incl.
+    7x7 reflect and transposed phases, Winograd, narrow maps, bf16x3) -- and the calls that follow take state 2."""
+    from faoctasr import ops
+    torch.manual_seed(5)
+    dev = "cuda"
+    ops.conv_precision = ops.PRECISIONS[precision]
+    try:
+        layers = []      # (kind of module, weight, args, input)
+        mk = lambda *s: torch.nn.Parameter(torch.randn(*s, device=dev) * 0.05)
+        layers.append(("conv", mk(64, 64, 3, 3), (1, 1, False), torch.randn(2, 64, 128, 128, device=dev)))      # Winograd / bf16x3
+        layers.append(("conv", mk(64, 32, 7, 7), (1, 3, True), torch.randn(2, 32, 64, 64, device=dev)))         # 7x7 reflect, LDS-patch
+        layers.append(("conv", mk(128, 64, 4, 4), (2, 1, False), torch.randn(2, 64, 64, 64, device=dev)))       # stride 2
+        layers.append(("conv", mk(256, 256, 3, 3), (1, 1, False), torch.randn(2, 256, 16, 16, device=dev)))     # narrow map
+        layers.append(("conv", mk(1, 64, 3, 3), (1, 1, False), torch.randn(2, 64, 64, 64, device=dev)))         # 64->1 head: no image
+        layers.append(("convT", mk(64, 32, 3, 3), (2, 1, 1), torch.randn(2, 64, 32, 32, device=dev)))           # transposed, 4 phases
+        layers.append(("convT", mk(64, 32, 4, 4), (2, 1, 0), torch.randn(2, 64, 32, 32, device=dev)))
+        params = [w for _, w, _, _ in layers]
+
+        def run_all():
+            outs = []
+            for kind, w, a, x in layers:
+                x = x.clone().requires_grad_(True)
+                y = ops.conv2d(x, w, None, a[0], a[1], a[2]) if kind == "conv" else ops.conv_transpose2d(x, w, None, a[0], a[1], a[2])
+                (gx,) = torch.autograd.grad(y.sum(), x)
+                outs += [y.detach(), gx]
+            return outs
+
+        run_all()                                                           # allocates the image buffers
+        ents = [e for e in ops._wpack_cache.values() if e.wref() is not None and any(e.wref() is p for p in params)]
+        assert len(ents) == 2 * len(layers)
+
+        def wipe():                                                         # buffers carry slack past the image: compare from a known state
+            for e in ents:
+                e.buf.zero_()
+                e.ver = None
+
+        wipe()
+        m0 = ops.pack_misses
+        ref_out = run_all()                                                 # every call packs its own image (state 1)
+        assert ops.pack_misses == m0 + len(ents)
+        ref_img = [e.buf.clone() for e in ents]
+        plan = ops.PackPlan(params, ops.conv_precision)
+        assert plan.njobs == len(ents) - 1 and plan.nblocks > 0              # the head's forward keeps no image; its dgrad does
+        wipe()
+        assert plan.run()
+        torch.cuda.synchronize()
+        n_checked = 0
+        for e, img in zip(ents, ref_img):
+            if e.kind == 0 and e.dims[4] == 1:
+                continue                                                    # never written, never read
+            assert img.abs().sum() > 0
+            assert torch.equal(e.buf.view(torch.int32), img.view(torch.int32)), (e.kind, e.dims)
+            n_checked += 1
+        assert n_checked == plan.njobs
+        m1 = ops.pack_misses
+        out = run_all()                                                     # state 2 everywhere
+        assert ops.pack_misses == m1
+        for a, b in zip(out, ref_out):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+        # a weight that moved invalidates the plan instead of packing from a stale address
+        params[0].data = params[0].data.clone()
+        assert not plan.run()
+    finally:
+        ops.conv_precision = 0
