@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
+    ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
     ap.add_argument("--force-launch", action="store_true", help="take the self-launch path (torch.distributed.run children) even for one GPU")
     ap.add_argument("--ddp-graph", action="store_true", help="data-parallel runs: also measure the hipGraph-captured step (RCCL inside the capture)")
     args = ap.parse_args()
@@ -249,7 +250,7 @@ def main():
     import random
     random.seed(1234 + rank)
     # distributed: TrainStep creates the RCCL communicator behind the C ABI and broadcasts rank 0's arenas / BN buffers
-    ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision)
+    ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision, overlap_wgrad=not args.no_overlap)
     B, H = args.batch, args.size
     real_A, real_B = make_batch(B, H, device, rank)
 
@@ -282,9 +283,11 @@ def main():
         timer = LaunchTimer(GATHER + WGRAD) if rank == 0 else None
         _lib.launch_timer = timer
         nroof = max(1, min(3, args.steps))
+        overlap, ts.overlap_wgrad = ts.overlap_wgrad, False          # one stream: each launch's events bracket that kernel alone
         for _ in range(nroof):
             ts.step(real_A, real_B)
         torch.cuda.synchronize()
+        ts.overlap_wgrad = overlap
         _lib.launch_timer = None
     if rank == 0 and not args.no_roofline:
         fams = timer.families(nroof)

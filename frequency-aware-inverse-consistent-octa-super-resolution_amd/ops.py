@@ -134,6 +134,33 @@ class PackPlan:
         return True
 
 
+#: Set by TrainStep for the span of a backward pass: weight / bias gradients that accumulate straight into the gradient arena are
+#: then enqueued on this second HIP stream (ordered after the main stream's work so far), so that they overlap the input-gradient
+#: chain, the BatchNorm backward passes and each other's launch tails instead of queueing behind them.  ``join_wgrad_stream`` makes
+#: the main stream wait for them (before the all-reduce / optimizer step).  Their operands stay referenced until then, so the
+#: caching allocator cannot hand an activation to a main-stream kernel while a side-stream kernel still reads it.
+wgrad_stream = None
+_wgrad_keep = []
+
+
+def _enqueue_wgrad(fn, *operands):
+    """``fn(stream_pointer)`` on ``wgrad_stream`` when one is set, otherwise on the current stream."""
+    side = wgrad_stream
+    if side is None:
+        fn(stream_ptr())
+        return
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(side.cuda_stream)
+    _wgrad_keep.append(operands)
+
+
+def join_wgrad_stream():
+    if wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(wgrad_stream)
+    _wgrad_keep.clear()
+
+
 def _grad_target(p):
     g = p.grad
     if direct_grad and g is not None and g.is_contiguous() and g.dtype == torch.float32:
@@ -194,14 +221,19 @@ class _Conv2d(Function):
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:
                 dw = torch.empty_like(w)
-            call("conv2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
-                 reflect, 1 if tgt is not None else 0, conv_precision, st)
+            prec = conv_precision
+            if tgt is not None:
+                _enqueue_wgrad(lambda s: call("conv2d_wgrad", ptr(x), ptr(dy), ptr(tgt), N, C, IH, IW, M, KH, KW, stride, pad, reflect, 1, prec, s),
+                               x, dy)
+            else:
+                call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, IH, IW, M, KH, KW, stride, pad, reflect, 0, prec, st)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
-            tgt = _grad_target(ctx.b_ref)
-            if tgt is None:
+            tb = _grad_target(ctx.b_ref)
+            if tb is not None:
+                _enqueue_wgrad(lambda s: call("channel_sum", ptr(dy), ptr(tb), N, M, dy.shape[2] * dy.shape[3], 1, s), dy)
+            else:
                 db = torch.empty(M, dtype=torch.float32, device=x.device)
-            call("channel_sum", ptr(dy), ptr(tgt if tgt is not None else db), N, M, dy.shape[2] * dy.shape[3],
-                 1 if tgt is not None else 0, st)
+                call("channel_sum", ptr(dy), ptr(db), N, M, dy.shape[2] * dy.shape[3], 0, st)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -249,14 +281,19 @@ class _ConvTranspose2d(Function):
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:
                 dw = torch.empty_like(w)
-            call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(tgt if tgt is not None else dw), N, C, IH, IW, M, KH, KW, stride, pad,
-                 out_pad, 1 if tgt is not None else 0, conv_precision, st)
+            prec = conv_precision
+            if tgt is not None:
+                _enqueue_wgrad(lambda s: call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(tgt), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, 1,
+                                              prec, s), x, dy)
+            else:
+                call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, 0, prec, st)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
-            tgt = _grad_target(ctx.b_ref)
-            if tgt is None:
+            tb = _grad_target(ctx.b_ref)
+            if tb is not None:
+                _enqueue_wgrad(lambda s: call("channel_sum", ptr(dy), ptr(tb), N, M, dy.shape[2] * dy.shape[3], 1, s), dy)
+            else:
                 db = torch.empty(M, dtype=torch.float32, device=x.device)
-            call("channel_sum", ptr(dy), ptr(tgt if tgt is not None else db), N, M, dy.shape[2] * dy.shape[3],
-                 1 if tgt is not None else 0, st)
+                call("channel_sum", ptr(dy), ptr(db), N, M, dy.shape[2] * dy.shape[3], 0, st)
         return dx, dw, db, None, None, None, None, None
 
 

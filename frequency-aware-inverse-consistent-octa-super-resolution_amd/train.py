@@ -143,7 +143,7 @@ class ParamArena:
 class TrainStep:
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
-                 process_group=None, distributed=None, init=True, precision="f32"):
+                 process_group=None, distributed=None, init=True, precision="f32", overlap_wgrad=True):
         """``precision``: "f32" = exact fp32 MFMA contraction (default); "bf16x3" = forward / input-gradient convolutions on
         the bf16 matrix cores with hi/lo-split operands (fp32-parity: step-0 losses within ~1e-4; weight gradients stay fp32)."""
         if precision not in ops.PRECISIONS:
@@ -171,6 +171,12 @@ class TrainStep:
         self._targets = {}
         self.device = dev
         self.comm = None
+        #: second HIP stream for the weight gradients (ops.wgrad_stream); ``overlap_wgrad=False`` keeps everything on one stream
+        self.overlap_wgrad = bool(overlap_wgrad)
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        #: the two discriminators' updates (train.py:242-269) share nothing: each runs forward and backward on its own stream, so
+        #: their small deep-layer kernels (4x4 .. 32x32 maps, far fewer blocks than CUs) fill the chip together
+        self._branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if dev.type == "cuda" else None
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
         if self.distributed:
             if dev.type != "cuda":
@@ -258,7 +264,12 @@ class TrainStep:
         set_requires_grad([self.netD_A, self.netD_B], False)
         self.opt_G.zero_grad()
         L = self.generator_loss(o, real_A, real_B)
-        L["loss_G"].backward()
+        ops.wgrad_stream = self._side if self.overlap_wgrad else None
+        try:
+            L["loss_G"].backward()
+        finally:
+            ops.join_wgrad_stream()
+            ops.wgrad_stream = None
         if self.distributed:
             self.opt_G.all_reduce(self.group, self.comm)
         self.opt_G.step(1.0 / self.world, None if _static is None else _static["hyper_G"])
@@ -266,11 +277,27 @@ class TrainStep:
         set_requires_grad([self.netD_A, self.netD_B], True)
         self.opt_D.zero_grad()
         fake_A = self.fake_A_buffer.push_and_pop(o["fake_A"]) if _static is None else self.fake_A_buffer.apply(o["fake_A"], *_static["plan_A"])
-        L["loss_D_A"] = ops.mse_loss(self.netD_A(real_A), ones, 0.5) + ops.mse_loss(self.netD_A(fake_A.detach()), zeros, 0.5)
-        L["loss_D_A"].backward()
         fake_B = self.fake_B_buffer.push_and_pop(o["fake_B"]) if _static is None else self.fake_B_buffer.apply(o["fake_B"], *_static["plan_B"])
-        L["loss_D_B"] = ops.mse_loss(self.netD_B(real_B), ones, 0.5) + ops.mse_loss(self.netD_B(fake_B.detach()), zeros, 0.5)
-        L["loss_D_B"].backward()
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        branches = self._branch if (self.overlap_wgrad and main is not None) else (None, None)
+        ops.wgrad_stream = self._side if self.overlap_wgrad else None
+        try:
+            for key, net, real, fake, st in (("loss_D_A", self.netD_A, real_A, fake_A, branches[0]), ("loss_D_B", self.netD_B, real_B, fake_B, branches[1])):
+                if st is None:
+                    L[key] = ops.mse_loss(net(real), ones, 0.5) + ops.mse_loss(net(fake.detach()), zeros, 0.5)
+                    L[key].backward()
+                    continue
+                st.wait_stream(main)
+                with torch.cuda.stream(st):                      # autograd runs each node's backward on its forward's stream
+                    L[key] = ops.mse_loss(net(real), ones, 0.5) + ops.mse_loss(net(fake.detach()), zeros, 0.5)
+                    L[key].backward()
+                L[key].record_stream(main)
+        finally:
+            for st in branches:
+                if st is not None:
+                    main.wait_stream(st)
+            ops.join_wgrad_stream()
+            ops.wgrad_stream = None
         if self.distributed:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])

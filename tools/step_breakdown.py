@@ -22,9 +22,9 @@ class Timer:
     def __init__(self):
         self.rec = []
 
-    def add(self, name, args, s, e):
+    def add(self, name, args, s, e, route):
         sh = args[4:13] if name.endswith("_fwd") else args[3:12]
-        self.rec.append((name, tuple(int(v) for v in sh), bench.conv_flops(name, args), s, e))
+        self.rec.append((name + ":" + bench.ROUTES.get(route, "route%d" % route), tuple(int(v) for v in sh), bench.conv_flops(name, args), s, e))
 
 
 def main():
@@ -52,9 +52,9 @@ def main():
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     tot = sum(v[1] for v in agg.values()) / n
     print("total conv-family ms/step %.2f" % tot)
-    print("%-24s %-44s %5s %9s %8s %7s %6s" % ("call", "N,C,IH,IW,M,KH,KW,stride,pad", "n/stp", "ms/step", "us/call", "TF/s", "%"))
+    print("%-40s %-36s %5s %9s %8s %7s %6s" % ("call", "N,C,IH,IW,M,KH,KW,stride,pad", "n/stp", "ms/step", "us/call", "TF/s", "%"))
     for (name, sh), (c, ms, fl) in rows:
-        print("%-24s %-44s %5d %9.3f %8.1f %7.1f %6.1f" % (name, ",".join(map(str, sh)), c // n, ms / n, 1e3 * ms / c, fl / ms / 1e9, 100 * ms / n / tot))
+        print("%-40s %-36s %5d %9.3f %8.1f %7.1f %6.1f" % (name, ",".join(map(str, sh)), c // n, ms / n, 1e3 * ms / c, fl / ms / 1e9, 100 * ms / n / tot))
 
 
 if __name__ == "__main__":
