@@ -415,6 +415,9 @@ static int launch_gather(const float* x, const float* w, const float* bias, floa
             if (ksplit > nchunks / 4) ksplit = nchunks / 4;
             if (ksplit < 1) ksplit = 1;
         }
+#ifdef FAOCTASR_NO_SPLITK
+        ksplit = 1;
+#endif
         if (ksplit > 1) {
             hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s);
             if (e != hipSuccess) return fail(FAOCTASR_EHIP, "memset y: %s", hipGetErrorString(e));

@@ -270,9 +270,19 @@ class TrainStep:
         finally:
             ops.join_wgrad_stream()
             ops.wgrad_stream = None
-        if self.distributed:
-            self.opt_G.all_reduce(self.group, self.comm)
-        self.opt_G.step(1.0 / self.world, None if _static is None else _static["hyper_G"])
+        hyper_G = None if _static is None else _static["hyper_G"]
+        g_update_aside = self.distributed and self.overlap_wgrad and self._side is not None
+        if g_update_aside:
+            # the generators' gradient exchange and AdamW touch nothing the discriminator phase reads (it sees the detached
+            # fakes and the D arenas): they run on the side stream under it and are joined at the end of the step
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                self.opt_G.all_reduce(self.group, self.comm)
+                self.opt_G.step(1.0 / self.world, hyper_G)
+        else:
+            if self.distributed:
+                self.opt_G.all_reduce(self.group, self.comm)
+            self.opt_G.step(1.0 / self.world, hyper_G)
         # (3) discriminators, train.py:242-269
         set_requires_grad([self.netD_A, self.netD_B], True)
         self.opt_D.zero_grad()
@@ -298,6 +308,8 @@ class TrainStep:
                     main.wait_stream(st)
             ops.join_wgrad_stream()
             ops.wgrad_stream = None
+        if g_update_aside:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
         if self.distributed:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])

@@ -103,9 +103,13 @@ def test_config4_rccl_shard_b32_and_run_to_run_spread(fa, O, rccl_world1):
     """BASELINE configs[3], one rank's share (32 images of the global 256): `TrainStep(distributed=True)` -- RCCL communicator
     created through faoctasr_comm_create, replica broadcast, faoctasr_grad_allreduce after each backward phase, AdamW with
     grad_scale 1/world -- against the plain step on the same inputs, and the plain step against itself.
-    The step is not bit-reproducible (fp32 atomics in split-K and weight-gradient accumulation): what is asserted is a bound
-    on the spread -- step-0 losses 2e-5 relative, gradient arenas 1e-4 relative L2 -- for the run-to-run pair, and the SAME
-    bound for the RCCL step, i.e. the exchange adds nothing beyond that noise."""
+    The step is not bit-reproducible: the split-K gather kernels of the narrow discriminator layers add their partial sums with
+    fp32 atomics, so a forward activation moves by ~1e-7 from run to run, and the few that sit within that distance of a
+    LeakyReLU / ReLU kink change side, which moves the gradients by a DISCRETE amount (tools/run_to_run.py at this batch: the
+    generator arena is either 2e-6 or 3.7e-4 away from another run, the discriminator arena takes the values 6e-7 .. 1.8e-4; with
+    the split-K paths compiled out, -DFAOCTASR_NO_SPLITK, every run agrees to 5e-7, and a repeated backward of ONE forward graph
+    to 2e-6: tools/probe/backward_repeat.py).  What is asserted is a bound on that spread -- step-0 losses 2e-5 relative, gradient
+    arenas 1e-3 relative L2 -- for the run-to-run pair, and the SAME bound for the RCCL step, i.e. the exchange adds nothing."""
     B, H = 32, 256
     a, b = O.synthetic_batch(B, H, seed=99)
     a, b = a.cuda(), b.cuda()
@@ -128,9 +132,9 @@ def test_config4_rccl_shard_b32_and_run_to_run_spread(fa, O, rccl_world1):
             assert rel(other[0][k], ref[0][k]) < 2e-5, (name, k, other[0][k], ref[0][k])
         for i in (1, 2):
             d = float((other[i].double() - ref[i].double()).norm() / ref[i].double().norm())
-            assert d < 1e-4, (name, "grad arena", i, d)
+            assert d < 1e-3, (name, "grad arena", i, d)
         for k in ref[4]:
-            assert rel(other[4][k], ref[4][k]) < 1e-4, (name, k)
+            assert rel(other[4][k], ref[4][k]) < 5e-4, (name, k)
         # AdamW's first update is lr*sign(g): a weight may move by 2*lr where a ~0 gradient changes sign, never by more
         assert float((other[3] - ref[3]).abs().max()) <= 2.0 * 1.3e-4 * 1.01 + 1e-7, name
 

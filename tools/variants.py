@@ -23,6 +23,17 @@ def obj(src, out, extra=()):
 def main():
     src, macro, values = sys.argv[1], sys.argv[2], sys.argv[3:]
     os.makedirs(OUT, exist_ok=True)
+    if "," in src:                       # the same macro in several sources: one variant library per value
+        srcs = src.split(",")
+        others = [s for s in B.SOURCES if s not in srcs]
+        with ThreadPoolExecutor(6) as ex:
+            base = list(ex.map(lambda s: obj(s, os.path.join(OUT, s + ".o")), others))
+            for v in values:
+                var = list(ex.map(lambda s: obj(s, os.path.join(OUT, "%s_%s_%s.o" % (s, macro, v)), ["-D%s=%s" % (macro, v)]), srcs))
+                lib = os.path.join(OUT, "libfaoctasr_%s_%s.so" % (macro, v))
+                subprocess.run(FLAGS + ["-shared"] + base + var + ["-ldl", "-o", lib], check=True)
+                print(lib)
+        return
     others = [s for s in B.SOURCES if s != src]
     with ThreadPoolExecutor(6) as ex:
         base = list(ex.map(lambda s: obj(s, os.path.join(OUT, s + ".o")), others))
