@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 }
 
 // backward reduce: s1 = sum dy', s2 = sum dy' * xhat, dy' = dy * act'(y);  y == NULL: mask from the recomputed pre-activation
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// HAS_Y: the activation derivative is taken from the saved output (tanh, or an activation after a residual add); otherwise from x.
+// Both backward kernels are held to 64 VGPRs (8 waves / SIMD): next to two 224-VGPR weight-gradient waves per SIMD -- the side
+// stream's wgrad_s1 blocks -- one such wave still fits, so the streaming passes run under the matrix work instead of after it.
+template <bool HAS_Y, int NU>
+__global__ __launch_bounds__(256, 8) void norm_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               const float* __restrict__ y, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ ws, int R, int Cg,
@@ -167,18 +171,18 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     float s1 = 0.f, s2 = 0.f;
     for_row_pieces(R, HW, r, e0, e1, [&](long base, long lo, long hi) {
         for (long i = lo + 4L * threadIdx.x; i < hi; i += 1024L * NU) {
-            float4 xv[NU], g[NU], yv[NU];
+            float4 xv[NU], g[NU], yv[HAS_Y ? NU : 1];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const long o = base + i + 1024L * u;
                 const bool ok = i + 1024L * u < hi;
                 xv[u] = ok ? ld4(x + o) : make_float4(mean, mean, mean, mean);
                 g[u] = ok ? ld4(dy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (masked && y) yv[u] = ok ? ld4(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_Y) yv[u] = ok ? ld4(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                if (masked) g[u] = act_mask4(g[u], y ? yv[u] : pre4(xv[u], gsc, bsh), act, slope);
+                if (masked) g[u] = act_mask4(g[u], HAS_Y ? yv[HAS_Y ? u : 0] : pre4(xv[u], gsc, bsh), act, slope);
                 s1 += g[u].x + g[u].y + g[u].z + g[u].w;
                 s2 += g[u].x * ((xv[u].x - mean) * invstd) + g[u].y * ((xv[u].y - mean) * invstd) + g[u].z * ((xv[u].z - mean) * invstd) +
                       g[u].w * ((xv[u].w - mean) * invstd);
@@ -193,7 +197,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool HAS_Y, int NU>
+__global__ __launch_bounds__(256, 8) void norm_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ y, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, float* __restrict__ dx,
@@ -226,20 +231,20 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const float* __restric
     e1 = e1 < L ? e1 : L;
     for_row_pieces(R, HW, r, e0, e1, [&](long base, long lo, long hi) {
         for (long i = lo + 4L * threadIdx.x; i < hi; i += 1024L * NU) {
-            float4 xv[NU], g[NU], yv[NU];
+            float4 xv[NU], g[NU], yv[HAS_Y ? NU : 1];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const long o = base + i + 1024L * u;
                 const bool ok = i + 1024L * u < hi;
                 xv[u] = ok ? ld4(x + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                 g[u] = ok ? ld4(dy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (masked && y) yv[u] = ok ? ld4(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_Y) yv[u] = ok ? ld4(y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 if (i + 1024L * u >= hi) continue;
                 const long o = base + i + 1024L * u;
-                if (masked) g[u] = act_mask4(g[u], y ? yv[u] : pre4(xv[u], gsc, bsh), act, slope);
+                if (masked) g[u] = act_mask4(g[u], HAS_Y ? yv[HAS_Y ? u : 0] : pre4(xv[u], gsc, bsh), act, slope);
                 if (dres) st4(dres + o, g[u]);
                 float4 d;
                 d.x = gi * (g[u].x - m1 - (xv[u].x - mean) * invstd * m2);
@@ -564,10 +569,13 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
     int S; long per;
     norm_split(L, R, S, per);
     if ((HW & 3) == 0) {
-        hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, ws, R, Cg, HW, L,
-                           S, act, slope, per);
-        hipLaunchKernelGGL(norm_bwd_dx_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta,
-                           dres, ws, R, Cg, HW, L, S, act, slope, per, accumulate);
+        auto go = [&](auto kr, auto kd) {
+            hipLaunchKernelGGL(kr, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, ws, R, Cg, HW, L, S, act, slope, per);
+            hipLaunchKernelGGL(kd, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, dres, ws, R, Cg,
+                               HW, L, S, act, slope, per, accumulate);
+        };
+        if (y && act != FAOCTASR_ACT_NONE) go(norm_bwd_reduce_kernel<true, 2>, norm_bwd_dx_kernel<true, 2>);
+        else go(norm_bwd_reduce_kernel<false, 4>, norm_bwd_dx_kernel<false, 4>);
     } else {
         hipLaunchKernelGGL(norm_bwd_reduce_generic_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, ws, R,
                            Cg, HW, L, S, act, slope, per);

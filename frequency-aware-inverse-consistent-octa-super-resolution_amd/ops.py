@@ -135,12 +135,13 @@ class PackPlan:
 
 
 #: Set by TrainStep for the span of a backward pass: weight / bias gradients that accumulate straight into the gradient arena are
-#: then enqueued on this second HIP stream (ordered after the main stream's work so far), so that they overlap the input-gradient
-#: chain, the BatchNorm backward passes and each other's launch tails instead of queueing behind them.  ``join_wgrad_stream`` makes
-#: the main stream wait for them (before the all-reduce / optimizer step).  Their operands stay referenced until then, so the
-#: caching allocator cannot hand an activation to a main-stream kernel while a side-stream kernel still reads it.
+#: then enqueued on this second HIP stream (ordered after the producing stream's work so far), so that they overlap the
+#: input-gradient chain, the BatchNorm backward passes and each other's launch tails instead of queueing behind them.
+#: ``join_wgrad_stream`` makes the current stream wait for them (before the all-reduce / optimizer step).  Their operands stay
+#: referenced until then, so the caching allocator cannot hand an activation to another kernel while a side-stream kernel still
+#: reads it.
 wgrad_stream = None
-_wgrad_keep = []
+_wgrad_keep = {}
 
 
 def _enqueue_wgrad(fn, *operands):
@@ -152,13 +153,14 @@ def _enqueue_wgrad(fn, *operands):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         fn(side.cuda_stream)
-    _wgrad_keep.append(operands)
+    _wgrad_keep.setdefault(side.cuda_stream, []).append(operands)
 
 
-def join_wgrad_stream():
-    if wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(wgrad_stream)
-    _wgrad_keep.clear()
+def join_wgrad_stream(side):
+    """The current stream waits for everything enqueued on ``side``; the operands held for it are released."""
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+        _wgrad_keep.pop(side.cuda_stream, None)
 
 
 def _grad_target(p):

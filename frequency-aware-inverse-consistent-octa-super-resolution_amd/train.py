@@ -174,6 +174,7 @@ class TrainStep:
         #: second HIP stream for the weight gradients (ops.wgrad_stream); ``overlap_wgrad=False`` keeps everything on one stream
         self.overlap_wgrad = bool(overlap_wgrad)
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._side_D = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         #: the two discriminators' updates (train.py:242-269) share nothing: each runs forward and backward on its own stream, so
         #: their small deep-layer kernels (4x4 .. 32x32 maps, far fewer blocks than CUs) fill the chip together
         self._branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if dev.type == "cuda" else None
@@ -250,47 +251,16 @@ class TrainStep:
         L["loss_G"] = total
         return L
 
-    def step(self, real_A, real_B, sync=False, keep=False, _static=None):
-        """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats).
-        ``_static`` (GraphedTrainStep): device tensors replacing the host-decided pieces -- replay-buffer index plans and AdamW scalars."""
-        B = real_A.shape[0]
-        ones, zeros = self.targets(B)
-        ops.conv_precision = ops.PRECISIONS[self.precision]
-        misses = ops.pack_misses
-        if self._pack_plan is not None and not self._pack_plan.run():     # every packed-weight image of the step in one launch
-            self._pack_plan = None
-        o = self.forward_generators(real_A, real_B)
-        # (2) generators, train.py:218-239
-        set_requires_grad([self.netD_A, self.netD_B], False)
-        self.opt_G.zero_grad()
-        L = self.generator_loss(o, real_A, real_B)
-        ops.wgrad_stream = self._side if self.overlap_wgrad else None
-        try:
-            L["loss_G"].backward()
-        finally:
-            ops.join_wgrad_stream()
-            ops.wgrad_stream = None
-        hyper_G = None if _static is None else _static["hyper_G"]
-        g_update_aside = self.distributed and self.overlap_wgrad and self._side is not None
-        if g_update_aside:
-            # the generators' gradient exchange and AdamW touch nothing the discriminator phase reads (it sees the detached
-            # fakes and the D arenas): they run on the side stream under it and are joined at the end of the step
-            self._side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self._side):
-                self.opt_G.all_reduce(self.group, self.comm)
-                self.opt_G.step(1.0 / self.world, hyper_G)
-        else:
-            if self.distributed:
-                self.opt_G.all_reduce(self.group, self.comm)
-            self.opt_G.step(1.0 / self.world, hyper_G)
-        # (3) discriminators, train.py:242-269
+    def _discriminator_phase(self, L, o, real_A, real_B, _static, branches, side):
+        """train.py:242-266 without the optimizer step: both discriminator losses and their backward passes.  ``branches``: one
+        stream per discriminator (their updates share nothing), ``side``: the stream for their weight gradients."""
+        ones, zeros = self.targets(real_A.shape[0])
         set_requires_grad([self.netD_A, self.netD_B], True)
         self.opt_D.zero_grad()
         fake_A = self.fake_A_buffer.push_and_pop(o["fake_A"]) if _static is None else self.fake_A_buffer.apply(o["fake_A"], *_static["plan_A"])
         fake_B = self.fake_B_buffer.push_and_pop(o["fake_B"]) if _static is None else self.fake_B_buffer.apply(o["fake_B"], *_static["plan_B"])
-        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        branches = self._branch if (self.overlap_wgrad and main is not None) else (None, None)
-        ops.wgrad_stream = self._side if self.overlap_wgrad else None
+        main = torch.cuda.current_stream(self.device) if branches[0] is not None else None
+        ops.wgrad_stream = side
         try:
             for key, net, real, fake, st in (("loss_D_A", self.netD_A, real_A, fake_A, branches[0]), ("loss_D_B", self.netD_B, real_B, fake_B, branches[1])):
                 if st is None:
@@ -303,13 +273,71 @@ class TrainStep:
                     L[key].backward()
                 L[key].record_stream(main)
         finally:
-            for st in branches:
-                if st is not None:
-                    main.wait_stream(st)
-            ops.join_wgrad_stream()
             ops.wgrad_stream = None
-        if g_update_aside:
-            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        return fake_A, fake_B            # alive until the branches are joined
+
+    def _join_discriminator_phase(self, branches, side):
+        main = torch.cuda.current_stream(self.device)
+        for st in branches:
+            if st is not None:
+                main.wait_stream(st)
+        ops.join_wgrad_stream(side)
+
+    def step(self, real_A, real_B, sync=False, keep=False, _static=None):
+        """One iteration of train.py:166-269.  Returns the losses as device scalars (``sync=True``: floats).
+        ``_static`` (GraphedTrainStep): device tensors replacing the host-decided pieces -- replay-buffer index plans and AdamW scalars.
+
+        Stream schedule (``overlap_wgrad``; the arithmetic and its order per tensor are the reference's): weight gradients go to a
+        side stream; the discriminator phase reads only the detached fakes and the discriminator weights -- nothing the generators'
+        backward produces -- so once every packed-weight image is current it is enqueued on two branch streams BEFORE
+        ``loss_G.backward()`` and its narrow-map, low-occupancy kernels run under the generators' large ones."""
+        ops.conv_precision = ops.PRECISIONS[self.precision]
+        misses = ops.pack_misses
+        packed = self._pack_plan is not None and self._pack_plan.run()     # every packed-weight image of the step in one launch
+        if not packed:
+            self._pack_plan = None
+        o = self.forward_generators(real_A, real_B)
+        # (2) generators, train.py:218-239
+        set_requires_grad([self.netD_A, self.netD_B], False)
+        self.opt_G.zero_grad()
+        L = self.generator_loss(o, real_A, real_B)
+        streams = self.overlap_wgrad and self._side is not None
+        side_G, side_D = (self._side, self._side_D) if streams else (None, None)
+        branches = self._branch if streams else (None, None)
+        # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
+        # needs them all written up front (the plan), i.e. not the first step / a step after the plan was dropped
+        early_D = streams and packed
+        held = None
+        try:
+            if early_D:
+                held = self._discriminator_phase(L, o, real_A, real_B, _static, branches, side_D)
+            ops.wgrad_stream = side_G
+            try:
+                L["loss_G"].backward()
+            finally:
+                ops.wgrad_stream = None
+                ops.join_wgrad_stream(side_G)
+            hyper_G = None if _static is None else _static["hyper_G"]
+            g_update_aside = self.distributed and streams
+            if g_update_aside:
+                # the generators' gradient exchange and AdamW touch nothing the discriminator phase reads: they run on the side
+                # stream under it and are joined before the discriminators' update
+                side_G.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side_G):
+                    self.opt_G.all_reduce(self.group, self.comm)
+                    self.opt_G.step(1.0 / self.world, hyper_G)
+            else:
+                if self.distributed:
+                    self.opt_G.all_reduce(self.group, self.comm)
+                self.opt_G.step(1.0 / self.world, hyper_G)
+            # (3) discriminators, train.py:242-269
+            if not early_D:
+                held = self._discriminator_phase(L, o, real_A, real_B, _static, branches, side_D)
+        finally:
+            if streams:
+                self._join_discriminator_phase(branches, side_D)
+                ops.join_wgrad_stream(side_G)
+        del held
         if self.distributed:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
