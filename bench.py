@@ -21,6 +21,7 @@ Beside the headline value the line carries
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -220,6 +221,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
+    ap.add_argument("--graph-only", action="store_true", help="(internal) measure only the hipGraph-captured step and print it")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
     ap.add_argument("--force-launch", action="store_true", help="take the self-launch path (torch.distributed.run children) even for one GPU")
     ap.add_argument("--ddp-graph", action="store_true", help="data-parallel runs: also measure the hipGraph-captured step (RCCL inside the capture)")
@@ -250,6 +252,8 @@ def main():
     import random
     random.seed(1234 + rank)
     # distributed: TrainStep creates the RCCL communicator behind the C ABI and broadcasts rank 0's arenas / BN buffers
+    if args.graph_only:
+        args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision, overlap_wgrad=not args.no_overlap)
     B, H = args.batch, args.size
     real_A, real_B = make_batch(B, H, device, rank)
@@ -340,7 +344,8 @@ def main():
                                          "parity": "step-0 losses within 1e-4, gradient norms within 2.3e-4 of the f32 path (tests/test_gpu_step.py)"}
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
     # (data-parallel: every rank captures and replays in lockstep, RCCL's kernels are graph nodes -- opt-in with --ddp-graph)
-    if not args.no_graph and ((rank == 0 and not distributed) or (distributed and args.ddp_graph)):
+    graph_note = "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"
+    if args.graph_only or (not args.no_graph and distributed and args.ddp_graph):
         gs = faoctasr.GraphedTrainStep(ts, real_A, real_B)
         for _ in range(2):
             gs.step(real_A, real_B)
@@ -351,8 +356,22 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         extra["hipgraph_step"] = {"value": round(world * B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
-                                  "note": "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"}
+                                  "note": graph_note}
         del gs
+        if args.graph_only:
+            print(json.dumps({"hipgraph_step": extra["hipgraph_step"]}), flush=True)
+            return
+    elif not args.no_graph and rank == 0 and not distributed:
+        # the secondary captured-step measurement runs in a child process: a fault inside the capture machinery (ROCm's
+        # hipStreamEndCapture has produced one during development) must not take the headline line with it
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--warmup", "2", "--batch", str(B),
+               "--size", str(H), "--precision", args.precision] + (["--no-overlap"] if args.no_overlap else [])
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            got = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+            extra["hipgraph_step"] = got[-1]["hipgraph_step"] if got else {"value": None, "note": "captured-step child exited with code %d" % r.returncode}
+        except Exception as e:             # timeout, unparsable output
+            extra["hipgraph_step"] = {"value": None, "note": "captured-step child failed: %s" % type(e).__name__}
     if rank == 0 and world == 1 and not args.no_roofline:
         extra["roofline_hbm"] = hbm_kernels(device)
     if distributed:
