@@ -366,10 +366,12 @@ def main():
         # hipStreamEndCapture has produced one during development) must not take the headline line with it
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--warmup", "2", "--batch", str(B),
                "--size", str(H), "--precision", args.precision] + (["--no-overlap"] if args.no_overlap else [])
+        torch.cuda.empty_cache()             # the child needs the same working set: hand the cached blocks back first
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             got = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
-            extra["hipgraph_step"] = got[-1]["hipgraph_step"] if got else {"value": None, "note": "captured-step child exited with code %d" % r.returncode}
+            extra["hipgraph_step"] = got[-1]["hipgraph_step"] if got else {
+                "value": None, "note": "captured-step child exited with code %d: %s" % (r.returncode, r.stderr.decode(errors="replace").strip().splitlines()[-1:])}
         except Exception as e:             # timeout, unparsable output
             extra["hipgraph_step"] = {"value": None, "note": "captured-step child failed: %s" % type(e).__name__}
     if rank == 0 and world == 1 and not args.no_roofline:

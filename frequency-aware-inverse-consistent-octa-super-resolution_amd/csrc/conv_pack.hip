@@ -24,10 +24,9 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const char* __rest
     const PackJob& J = *reinterpret_cast<const PackJob*>(jobs + (size_t)lo * PACK_JOB_BYTES);
     const long lb = b - J.block0;
     if (lb >= J.blocks) return;                    // cannot happen for a table built by faoctasr_conv_pack_job; keeps a bad table harmless
-    const long first = lb * 256 + threadIdx.x, stride = (long)J.blocks * 256;
-    if (J.type == PACK_PATCH) patch_pack_elems(J.w, J.wp, J.g.patch, J.total, first, stride);
-    else if (J.type == PACK_WINO) wino_pack_elems(J.w, J.wp, J.g.wino, J.total, first, stride);
-    else if (J.type == PACK_SPLIT) split_pack_elems(J.w, reinterpret_cast<__bf16*>(J.wp), J.g.split, J.total, first, stride);
+    if (J.type == PACK_PATCH) patch_pack_block(J.w, J.wp, J.g.patch, lb, J.blocks);
+    else if (J.type == PACK_WINO) wino_pack_block(J.w, J.wp, J.g.wino, lb, J.blocks);
+    else if (J.type == PACK_SPLIT) split_pack_block(J.w, reinterpret_cast<__bf16*>(J.wp), J.g.split, lb, J.blocks);
 }
 
 }  // namespace faoctasr

@@ -461,12 +461,12 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
     if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     if (wpack && wpack_state && precision == 2) {
         const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
-        if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total); return FAOCTASR_OK; }
+        if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total / (8L * sink->g.split.Mpad)); return FAOCTASR_OK; }
         if (rc != 0) { set_route(ROUTE_BF16X3); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state && precision == 0) {
         const int rc = wino_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
-        if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total); return FAOCTASR_OK; }
+        if (rc != 0 && sink) { sink->blocks = pack_job_blocks((long)sink->g.wino.mtiles * sink->g.wino.nchunks); return FAOCTASR_OK; }
         if (rc != 0) { set_route(ROUTE_WINOGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     if (wpack && wpack_state) {
@@ -475,7 +475,7 @@ static int run_gather(const float* x, const float* w, const float* bias, float* 
         if (rc) return rc;
         if (sink) {
             sink->type = PACK_PATCH; sink->w = w; sink->wp = wpack; sink->g.patch = pg; sink->total = pg.pack_off[4];
-            sink->blocks = pack_job_blocks(sink->total);
+            sink->blocks = pack_job_blocks(sink->total / pg.Mpad);
             return FAOCTASR_OK;
         }
         if (wpack_state == 1) {

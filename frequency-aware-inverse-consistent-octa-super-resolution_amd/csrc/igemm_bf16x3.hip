@@ -53,8 +53,8 @@ __device__ __forceinline__ void wait_keep_next(bf16x8 (&a)[MI][2], bf16x8 (&b)[N
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing: fp32 W (arbitrary m / c strides, tap list) -> two bf16 planes in the LDS image order
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom g, long total) {
-    split_pack_elems(w, wp, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom g) {
+    split_pack_block(w, wp, g, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -436,9 +436,7 @@ long split_pack_floats(const SplitGeom& g) { return g.plane_stride + 512; }   //
 int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t s) {
     const long total = g.pack_off[4];
     if (total <= 0) return FAOCTASR_OK;
-    long blocks = (total + 255) / 256;
-    blocks = blocks > 4096 ? 4096 : blocks;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp), g, total);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp), g);
     return check_launch("split_pack");
 }
 

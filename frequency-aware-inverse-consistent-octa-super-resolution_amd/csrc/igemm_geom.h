@@ -61,7 +61,7 @@ struct SplitGeom {
 enum PackType { PACK_PATCH = 0, PACK_WINO = 1, PACK_SPLIT = 2 };
 struct PackJob {
     long block0;                   // first block of this job in the batched grid
-    long total;                    // packed elements
+    long total;                    // packed elements (0: nothing to pack)
     const float* w;
     float* wp;
     int type, blocks;
@@ -73,10 +73,7 @@ struct PackJob {
 };
 constexpr int PACK_JOB_BYTES = 1024;
 static_assert(sizeof(PackJob) <= PACK_JOB_BYTES, "PackJob outgrew its slot");
-inline int pack_job_blocks(long total) {
-    long b = (total + 255) / 256;
-    return (int)(b > 1024 ? 1024 : b);
-}
+inline int pack_job_blocks(long rows) { return (int)(rows > 1024 ? 1024 : rows); }      // a block owns whole rows of the image (pack_bodies.h)
 
 int patch_geom_from(const IgemmGeom& f, PatchGeom& g);
 long patch_pack_floats(const PatchGeom& g);

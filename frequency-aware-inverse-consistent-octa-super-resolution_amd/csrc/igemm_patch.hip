@@ -77,8 +77,8 @@ __device__ __forceinline__ void wait_frags_all(float (&a)[MI], float (&b)[NI]) {
 }
 
 // pack kernel: one thread per packed element (pack_bodies.h)
-__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, const PatchGeom g, long total) {
-    patch_pack_elems(w, wp, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, const PatchGeom g) {
+    patch_pack_block(w, wp, g, blockIdx.x, gridDim.x);
 }
 
 template <int WM, int WN, int MI, int NI, int SI, int DENSE = 0, int KCS = 2>
@@ -438,9 +438,7 @@ long patch_pack_floats(const PatchGeom& g) { return g.pack_off[4] + 256; }   // 
 int launch_pack(const float* w, float* wp, const PatchGeom& g, hipStream_t s) {
     const long total = g.pack_off[4];
     if (total <= 0) return FAOCTASR_OK;
-    long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, wp, g, total);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)pack_job_blocks(total / g.Mpad)), dim3(256), 0, s, w, wp, g);
     return check_launch("conv_pack");
 }
 

@@ -67,8 +67,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // U = G g G^T, written in the order the kernel's weight waves want: [mtile][chunk][xi][k][m][j], c = chunk*8 + k + 4j (pack_bodies.h)
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, const WinoGeom g, long total) {
-    wino_pack_elems(w, up, g, total, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ up, const WinoGeom g) {
+    wino_pack_block(w, up, g, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict__ x, const float* __restrict__ up,
@@ -506,10 +506,7 @@ int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bi
         return 1;
     }
     if (wpack_state == 1) {
-        const long total = (long)g.mtiles * g.nchunks * WN_U_FLOATS;
-        long blocks = (total + 255) / 256;
-        blocks = blocks > 4096 ? 4096 : blocks;
-        hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, wpack, g, total);
+        hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pack_job_blocks((long)g.mtiles * g.nchunks)), dim3(256), 0, s, w, wpack, g);
         const int rc = check_launch("wino_pack");
         if (rc) return rc;
     }
