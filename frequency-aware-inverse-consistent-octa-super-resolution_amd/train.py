@@ -206,22 +206,42 @@ class TrainStep:
             self._targets[B] = t
         return t
 
-    def forward_generators(self, real_A, real_B):
-        """train.py:173-214."""
+    def forward_generators(self, real_A, real_B, critics=None):
+        """train.py:173-214.  ``critics`` = (stream for netD_A, stream for netD_B): the frozen discriminators' passes of the adversarial
+        terms (train.py:221-222) are enqueued on those streams as soon as their fake exists, so that their narrow-map kernels run under
+        the remaining generator passes (and, because autograd replays a node on its forward's stream, under the generators' backward)."""
         G_A2B, G_B2A = self.netG_A2B, self.netG_B2A
         o = {}
+
+        def critic(net, fake, st, key):
+            if st is None:
+                return
+            main = torch.cuda.current_stream(self.device)
+            st.wait_stream(main)
+            fake.record_stream(st)
+            with torch.cuda.stream(st):
+                o[key] = net(fake)
+            o[key].record_stream(main)
+
         hf, lf = ops.freq_split(real_A, 10, 8)
         _, hf_feature_A, o["fake_B"] = G_A2B(lf, hf)
+        if critics:
+            critic(self.netD_B, o["fake_B"], critics[1], "pred_fake_B")
         _, _, o["idt_A"] = G_B2A(hf, lf)
         o["hf_feature_A"] = hf_feature_A.detach()
         hf, lf = ops.freq_split(o["fake_B"], 5, 14)
         o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)
         hf, lf = ops.freq_split(real_B, 5, 14)
         hf_feature_B, _, o["fake_A"] = G_B2A(hf, lf)
+        if critics:
+            critic(self.netD_A, o["fake_A"], critics[0], "pred_fake_A")
         _, _, o["idt_B"] = G_A2B(lf, hf)
         o["hf_feature_B"] = hf_feature_B.detach()
         hf, lf = ops.freq_split(o["fake_A"], 10, 8)
         _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)
+        if critics:
+            for st in critics:
+                torch.cuda.current_stream(self.device).wait_stream(st)
         return o
 
     def generator_loss(self, o, real_A, real_B):
@@ -229,8 +249,8 @@ class TrainStep:
         w = self.w
         ones, _ = self.targets(real_A.shape[0])
         L = {}
-        L["loss_GAN_A2B"] = ops.mse_loss(self.netD_B(o["fake_B"]), ones, w["beta4"])
-        L["loss_GAN_B2A"] = ops.mse_loss(self.netD_A(o["fake_A"]), ones, w["beta5"])
+        L["loss_GAN_A2B"] = ops.mse_loss(o["pred_fake_B"] if "pred_fake_B" in o else self.netD_B(o["fake_B"]), ones, w["beta4"])
+        L["loss_GAN_B2A"] = ops.mse_loss(o["pred_fake_A"] if "pred_fake_A" in o else self.netD_A(o["fake_A"]), ones, w["beta5"])
         L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
         L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
             ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
@@ -296,12 +316,12 @@ class TrainStep:
         packed = self._pack_plan is not None and self._pack_plan.run()     # every packed-weight image of the step in one launch
         if not packed:
             self._pack_plan = None
-        o = self.forward_generators(real_A, real_B)
+        streams = self.overlap_wgrad and self._side is not None
+        set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
+        o = self.forward_generators(real_A, real_B, self._branch if (streams and packed) else None)
         # (2) generators, train.py:218-239
-        set_requires_grad([self.netD_A, self.netD_B], False)
         self.opt_G.zero_grad()
         L = self.generator_loss(o, real_A, real_B)
-        streams = self.overlap_wgrad and self._side is not None
         side_G, side_D = (self._side, self._side_D) if streams else (None, None)
         branches = self._branch if streams else (None, None)
         # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
