@@ -57,7 +57,7 @@ def conv_flops(name, a):
     return 2.0 * N * C * IH * IW * M * KH * KW          # transposed: every input pixel meets every tap
 
 
-ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 6: "narrow", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad",
+ROUTES = {1: "gather_flat", 2: "patch", 3: "winograd", 4: "bf16x3", 5: "m1_head", 6: "narrow", 7: "stem_dgrad", 16: "stem_wgrad", 11: "wgrad_flat", 12: "wgrad_patch", 13: "wgrad_s1", 14: "m1_wgrad",
           15: "wgrad_x3"}
 KERNEL_OF = {"narrow": "igemm_nm_kernel (GEMM-shaped implicit GEMM on the packed weights, maps narrower than 24)",
              "gather_flat": "igemm_gather_kernel<64> (flat implicit GEMM, maps narrower than 24)",
@@ -65,9 +65,11 @@ KERNEL_OF = {"narrow": "igemm_nm_kernel (GEMM-shaped implicit GEMM on the packed
              "winograd": "igemm_wino_kernel (Winograd F(2x2,3x3), stride-1 3x3 forward + input gradient)",
              "bf16x3": "igemm_bf16x3_kernel (hi/lo-split operands on v_mfma_f32_32x32x16_bf16)",
              "m1_head": "conv_m1_fwd_kernel (64 -> 1 head, VALU)",
+             "stem_dgrad": "stem_dgrad_kernel (4x4 stride-2 stems with 1..4 input channels, input gradient, VALU)",
+             "stem_wgrad": "stem_wgrad_kernel (4x4 stride-2 stems with 1..4 input channels, weight gradient, VALU)",
              "wgrad_flat": "igemm_wgrad_kernel (flat weight gradient, narrow maps)",
              "wgrad_patch": "wgrad_patch_kernel (LDS-patch weight gradient: stride 2, ragged shapes)",
-             "wgrad_s1": "wgrad_s1_kernel (stride-1 weight gradient, staging pipelined inside the MFMA loop)",
+             "wgrad_s1": "wgrad_s1_kernel (stride-1 / 4x4 stride-2 weight gradient, staging pipelined inside the MFMA loop)",
              "m1_wgrad": "conv_m1_wgrad_kernel (64 -> 1 head, VALU)",
              "wgrad_x3": "wgrad_x3_kernel (bf16x3 weight gradient, stride-1 3x3: transposed-read X image)"}
 #: share of the algorithmic (direct-convolution) FLOP a family really executes on the matrix pipe

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["igemm.hip", "igemm_patch.hip", "igemm_bf16x3.hip", "igemm_wino.hip", "igemm_nm.hip", "wgrad_patch.hip", "wgrad_s1.hip", "wgrad_x3.hip", "conv_m1.hip", "pointwise.hip", "norm.hip", "sgemm.hip",
-           "ssim.hip", "eval.hip", "comm.hip", "conv_pack.hip"]
+           "ssim.hip", "eval.hip", "comm.hip", "conv_pack.hip", "conv_stem.hip"]
 HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_geom.h"), os.path.join(HERE, "csrc", "pack_bodies.h"), os.path.join(ROOT, "include", "faoctasr.h")]
 #: per-source extra flags.  ssim.hip: the SLP vectoriser re-packs the scalar 11-tap filters into v_pk_fma_f32, which has the FLOP
 #: rate of two v_fma_f32 here and costs ~85 v_mov per filtered row to keep operands in aligned register pairs

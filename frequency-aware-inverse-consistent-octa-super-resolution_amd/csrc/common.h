@@ -11,7 +11,7 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 // which kernel family the last convolution-type call of this thread was dispatched to (diagnostics: faoctasr_last_route)
 enum Route { ROUTE_NONE = 0, ROUTE_GATHER_FLAT = 1, ROUTE_PATCH = 2, ROUTE_WINOGRAD = 3, ROUTE_BF16X3 = 4, ROUTE_M1_FWD = 5, ROUTE_NARROW = 6,
-             ROUTE_WGRAD_FLAT = 11, ROUTE_WGRAD_PATCH = 12, ROUTE_WGRAD_S1 = 13, ROUTE_M1_WGRAD = 14, ROUTE_WGRAD_X3 = 15 };
+             ROUTE_WGRAD_FLAT = 11, ROUTE_WGRAD_PATCH = 12, ROUTE_WGRAD_S1 = 13, ROUTE_M1_WGRAD = 14, ROUTE_WGRAD_X3 = 15, ROUTE_STEM_DGRAD = 7, ROUTE_STEM_WGRAD = 16 };
 void set_route(int r);
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute is issued once per (kernel, size step), not

@@ -547,6 +547,7 @@ long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const flo
             break;
         case 1:
             OH = (IH + 2 * pad - KH) / stride + 1; OW = (IW + 2 * pad - KW) / stride + 1;
+            if (stem_dgrad_eligible(C, IH, IW, M, KH, KW, stride, pad)) return 0;                    // VALU stem: reads the weights in place
             rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, kk, (long)C * kk);
             break;
         case 2:
@@ -594,6 +595,10 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
+    {
+        const int rc = launch_stem_dgrad(dy, w, dx, N, C, IH, IW, M, KH, KW, stride, pad, (hipStream_t)stream);
+        if (rc != 0) { set_route(ROUTE_STEM_DGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
+    }
     IgemmGeom g;
     // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
     int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
@@ -611,6 +616,10 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     {
         set_route(ROUTE_M1_WGRAD);
         return launch_conv_m1_wgrad(x, dy, dw, N, C, IH, IW, KH, KW, pad, accumulate, (hipStream_t)stream);
+    }
+    {
+        const int rc = launch_stem_wgrad(x, dy, dw, N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, (hipStream_t)stream);
+        if (rc != 0) { set_route(ROUTE_STEM_WGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
     }
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);

@@ -107,4 +107,11 @@ int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float*
 int launch_conv_m1_wgrad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, int KH, int KW, int pad, int accumulate,
                          hipStream_t st);
 
+// 4x4 stride-2 stems with 1..4 input channels on the VALU (conv_stem.hip): 1 launched, 0 not this shape, <0 error
+bool stem_dgrad_eligible(int C, int IH, int IW, int M, int KH, int KW, int stride, int pad);
+int launch_stem_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                      hipStream_t s);
+int launch_stem_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                      int reflect, int accumulate, hipStream_t s);
+
 }  // namespace faoctasr

@@ -81,6 +81,11 @@ CONV_CASES = [
     # stride-2 4x4 weight gradient through wgrad_s1.hip (S = 2): output map 32 / 64 / 96 wide, top / bottom / left / right borders
     (2, 16, 12, 64, 64, 4, 2, 1, False, True, None),          # one tile column, 3 tile rows (6 output rows)
     (2, 24, 64, 192, 128, 4, 2, 1, False, False, None),       # 3 tile columns (border, interior, border), two row blocks, 384 columns
+    # 4x4 stride-2 stems with 1..4 input channels: VALU input / weight gradient (conv_stem.hip)
+    (3, 1, 20, 44, 128, 4, 2, 1, False, False, None),         # ragged 10 x 22 map (partial tile rows and columns), M = 128
+    (2, 2, 36, 72, 42, 4, 2, 1, False, True, None),           # C = 2, M not a multiple of the channel group
+    (1, 4, 8, 8, 8, 4, 2, 1, False, False, None),             # C = 4, a map smaller than one tile
+    (8, 1, 256, 256, 64, 4, 2, 1, False, False, "lrelu"),     # the benchmark's discriminator stem
 ]
 
 
@@ -572,6 +577,8 @@ GUARD_CASES = [
     (2, 24, 40, 72, 96, 3, 1, 1),      # Winograd / patch config C
     (2, 64, 64, 96, 128, 3, 2, 1),     # patch kernel, stride 2
     (2, 512, 4, 4, 512, 4, 1, 1),      # flat kernel with split-K
+    (2, 1, 20, 44, 72, 4, 2, 1),       # 4x4 stride-2 stem: VALU input / weight gradient, ragged map
+    (2, 3, 64, 64, 64, 4, 2, 1),       # 3-channel stem
 ]
 
 

@@ -11,7 +11,7 @@ import sys
 
 FAMILY = [("igemm_wino_kernel", "winograd"), ("igemm_patch_kernel", "patch"), ("igemm_gather_kernel", "gather_flat"), ("igemm_nm_kernel", "narrow"), ("igemm_bf16x3_kernel", "bf16x3"),
           ("conv_m1_fwd", "m1_head"), ("igemm_wgrad_kernel", "wgrad_flat"), ("wgrad_patch_kernel", "wgrad_patch"), ("wgrad_s1_kernel", "wgrad_s1"),
-          ("wgrad_x3_kernel", "wgrad_x3"), ("conv_m1_wgrad", "m1_wgrad"), ("norm_", "norm"), ("haar_", "haar"), ("ssim_", "ssim")]
+          ("wgrad_x3_kernel", "wgrad_x3"), ("conv_m1_wgrad", "m1_wgrad"), ("stem_dgrad", "stem_dgrad"), ("stem_wgrad", "stem_wgrad"), ("norm_", "norm"), ("haar_", "haar"), ("ssim_", "ssim")]
 
 
 def family(name):
