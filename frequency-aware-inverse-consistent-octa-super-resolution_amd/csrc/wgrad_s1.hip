@@ -381,6 +381,10 @@ static bool s1_fits(const WgS1Geom& g, size_t* lds_out) {
     return true;
 }
 
+#ifndef S1_SLOTS
+#define S1_SLOTS 512          // tools/variants.py experiments: pixel slices per output tile = S1_SLOTS / (output tiles)
+#endif
+
 template <int WK, int NI, int S>
 static int s1_launch(const float* x, const float* dy, float* dw, WgS1Geom g, size_t lds, hipStream_t s) {
     constexpr int CT = (4 / WK) * NI * 32;
@@ -388,7 +392,7 @@ static int s1_launch(const float* x, const float* dy, float* dw, WgS1Geom g, siz
     g.gy = g.M / 64;
     const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
     // one residency round: 256 CUs x 2 blocks; split the pixel tiles so that gx*gy*slices just fits
-    long slices = 512 / ((long)g.gx * g.gy);
+    long slices = S1_SLOTS / ((long)g.gx * g.gy);
     if (slices < 1) slices = 1;
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
