@@ -283,3 +283,26 @@ def test_train_step_bench_workload_vs_oracle(fa, O):
         for k in gn:
             assert gn[k] == pytest.approx(go[k], rel=2e-3), (prec, k, gn[k], go[k])
         assert float(fa.psnr(L["tensors"]["recovered_A"], a.cuda())) == pytest.approx(psnr_o, rel=1e-3)
+
+
+@pytest.mark.gpu
+def test_train_step_non_square_vs_oracle(fa, O):
+    """A ragged input: 192 x 256 images, batch 3 (odd), two steps against the CPU oracle -- the frequency split with different row /
+    column circulants, Haar levels, every convolution route and the BatchNorm kernels on non-square maps, and from step 1 on the
+    full stream schedule (batched packs, discriminator work on branch streams)."""
+    random.seed(1234)
+    n = build_nets(fa, O)
+    ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"])
+    S = O.StepOracle(seed=0)
+    torch.set_num_threads(host_threads())
+    g = torch.Generator().manual_seed(77)
+    for step in range(2):
+        a = torch.rand(3, 1, 192, 256, generator=g) * 2 - 1
+        b = torch.rand(3, 1, 192, 256, generator=g) * 2 - 1
+        L = ts.step(a.cuda(), b.cuda(), sync=True)
+        Lo = S.train_step(a, b)
+        _check_step(L, Lo, step)
+        if step == 0:
+            gn, go = ts.grad_norms(), S.grad_norms()
+            for k in gn:
+                assert gn[k] == pytest.approx(go[k], rel=2e-3), k
