@@ -178,6 +178,7 @@ class TrainStep:
         #: the two discriminators' updates (train.py:242-269) share nothing: each runs forward and backward on its own stream, so
         #: their small deep-layer kernels (4x4 .. 32x32 maps, far fewer blocks than CUs) fill the chip together
         self._branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if dev.type == "cuda" else None
+        self._idt = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
         if self.distributed:
             if dev.type != "cuda":
@@ -206,46 +207,79 @@ class TrainStep:
             self._targets[B] = t
         return t
 
-    def forward_generators(self, real_A, real_B, critics=None):
+    def forward_generators(self, real_A, real_B, critics=None, idt=None):
         """train.py:173-214.  ``critics`` = (stream for netD_A, stream for netD_B): the frozen discriminators' passes of the adversarial
         terms (train.py:221-222) are enqueued on those streams as soon as their fake exists, so that their narrow-map kernels run under
-        the remaining generator passes (and, because autograd replays a node on its forward's stream, under the generators' backward)."""
+        the remaining generator passes (and, because autograd replays a node on its forward's stream, under the generators' backward).
+        ``idt`` = (stream, weight-gradient stream): each identity pass (train.py:177,200) runs on that stream together with its own loss
+        term AND that term's backward -- a third of the generators' backward work then runs under their forward, which has no other
+        concurrent partner (gradients add linearly and are accumulated with atomics, so the split of ``loss_G.backward()`` into
+        three calls changes no value beyond summation order).  A network's BatchNorm running statistics still see its three passes
+        in the reference's order: the main stream waits for the identity pass's forward before that network's next pass."""
         G_A2B, G_B2A = self.netG_A2B, self.netG_B2A
         o = {}
+        main = torch.cuda.current_stream(self.device) if (critics or idt) else None
 
         def critic(net, fake, st, key):
             if st is None:
                 return
-            main = torch.cuda.current_stream(self.device)
             st.wait_stream(main)
             fake.record_stream(st)
             with torch.cuda.stream(st):
                 o[key] = net(fake)
             o[key].record_stream(main)
 
+        def identity(net, first, second, real, key):
+            """``o[key]`` = third output of net(first, second); with ``idt`` also its loss term and that term's backward."""
+            if idt is None:
+                _, _, o[key] = net(first, second)
+                return None
+            st, side = idt
+            st.wait_stream(main)
+            for t in (first, second, real):
+                t.record_stream(st)
+            with torch.cuda.stream(st):
+                _, _, o[key] = net(first, second)
+                ev = st.record_event()
+                term = ops.l1_loss(real, o[key], self.w["beta2"])           # train.py:230-231
+                ops.wgrad_stream = side
+                try:
+                    term.backward()
+                finally:
+                    ops.wgrad_stream = None
+            o[key].record_stream(main)
+            term.record_stream(main)
+            o["loss_" + key] = term.detach()
+            return ev
+
         hf, lf = ops.freq_split(real_A, 10, 8)
+        ev = identity(G_B2A, hf, lf, real_A, "idt_A")                        # netG_B2A's first pass of the step
         _, hf_feature_A, o["fake_B"] = G_A2B(lf, hf)
         if critics:
             critic(self.netD_B, o["fake_B"], critics[1], "pred_fake_B")
-        _, _, o["idt_A"] = G_B2A(hf, lf)
         o["hf_feature_A"] = hf_feature_A.detach()
         hf, lf = ops.freq_split(o["fake_B"], 5, 14)
+        if ev is not None:
+            main.wait_event(ev)
         o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)
         hf, lf = ops.freq_split(real_B, 5, 14)
         hf_feature_B, _, o["fake_A"] = G_B2A(hf, lf)
         if critics:
             critic(self.netD_A, o["fake_A"], critics[0], "pred_fake_A")
-        _, _, o["idt_B"] = G_A2B(lf, hf)
+        ev = identity(G_A2B, lf, hf, real_B, "idt_B")                        # netG_A2B's second pass (after fake_B, before recovered_B)
         o["hf_feature_B"] = hf_feature_B.detach()
         hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        if ev is not None:
+            main.wait_event(ev)
         _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)
         if critics:
             for st in critics:
-                torch.cuda.current_stream(self.device).wait_stream(st)
+                main.wait_stream(st)
         return o
 
     def generator_loss(self, o, real_A, real_B):
-        """train.py:221-236 (+ the opt-in SSIM term of the commented line train.py:234 and a wavelet-HF L1 term)."""
+        """train.py:221-236 (+ the opt-in SSIM term of the commented line train.py:234 and a wavelet-HF L1 term).  ``L["_root"]`` is
+        what remains to be back-propagated (everything, unless ``forward_generators`` already did the identity terms)."""
         w = self.w
         ones, _ = self.targets(real_A.shape[0])
         L = {}
@@ -254,8 +288,14 @@ class TrainStep:
         L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
         L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
             ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
-        L["loss_idt"] = ops.l1_loss(real_A, o["idt_A"], w["beta2"]) + ops.l1_loss(real_B, o["idt_B"], w["beta2"])
-        total = L["loss_GAN_A2B"] + L["loss_GAN_B2A"] + L["loss_cycle_ABA"] + L["loss_cycle_BAB"] + L["loss_idt"]
+        total = L["loss_GAN_A2B"] + L["loss_GAN_B2A"] + L["loss_cycle_ABA"] + L["loss_cycle_BAB"]
+        done = None
+        if "loss_idt_A" in o:
+            done = o["loss_idt_A"] + o["loss_idt_B"]
+            L["loss_idt"] = done
+        else:
+            L["loss_idt"] = ops.l1_loss(real_A, o["idt_A"], w["beta2"]) + ops.l1_loss(real_B, o["idt_B"], w["beta2"])
+            total = total + L["loss_idt"]
         if self.ssim_weight:
             L["loss_ssim"] = self.ssim_weight * ((1 - ops.ssim(o["recovered_A"], real_A)) + (1 - ops.ssim(o["recovered_B"], real_B)))
             total = total + L["loss_ssim"]
@@ -268,7 +308,8 @@ class TrainStep:
                     t = t + ops.l1_loss(a, b, self.whf_weight)
             L["loss_whf"] = t
             total = total + t
-        L["loss_G"] = total
+        L["_root"] = total
+        L["loss_G"] = total if done is None else total.detach() + done
         return L
 
     def _discriminator_phase(self, L, o, real_A, real_B, _static, branches, side):
@@ -318,10 +359,12 @@ class TrainStep:
             self._pack_plan = None
         streams = self.overlap_wgrad and self._side is not None
         set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
-        o = self.forward_generators(real_A, real_B, self._branch if (streams and packed) else None)
+        self.opt_G.zero_grad()                                              # train.py:220 (before the first backward of a generator term)
+        multi = streams and packed
+        o = self.forward_generators(real_A, real_B, self._branch if multi else None, (self._idt, self._side) if multi else None)
         # (2) generators, train.py:218-239
-        self.opt_G.zero_grad()
         L = self.generator_loss(o, real_A, real_B)
+        root = L.pop("_root")
         side_G, side_D = (self._side, self._side_D) if streams else (None, None)
         branches = self._branch if streams else (None, None)
         # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
@@ -333,9 +376,11 @@ class TrainStep:
                 held = self._discriminator_phase(L, o, real_A, real_B, _static, branches, side_D)
             ops.wgrad_stream = side_G
             try:
-                L["loss_G"].backward()
+                root.backward()
             finally:
                 ops.wgrad_stream = None
+                if multi:                        # the identity terms' backward ran on their own stream (BatchNorm affine gradients there)
+                    torch.cuda.current_stream(self.device).wait_stream(self._idt)
                 ops.join_wgrad_stream(side_G)
             hyper_G = None if _static is None else _static["hyper_G"]
             g_update_aside = self.distributed and streams
