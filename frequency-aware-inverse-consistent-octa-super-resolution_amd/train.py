@@ -179,6 +179,7 @@ class TrainStep:
         #: their small deep-layer kernels (4x4 .. 32x32 maps, far fewer blocks than CUs) fill the chip together
         self._branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if dev.type == "cuda" else None
         self._idt = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._aba = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
         if self.distributed:
             if dev.type != "cuda":
@@ -277,6 +278,98 @@ class TrainStep:
                 main.wait_stream(st)
         return o
 
+    def _generators_two_chains(self, real_A, real_B):
+        """The generator phase (train.py:173-236) as two chains on two streams, for the plain loss (no SSIM / wavelet terms):
+
+            chain A (stream ``_aba``):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
+            chain B (main stream)    :  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
+            identity passes (``_idt``) and the frozen discriminator passes (branch streams) as in ``forward_generators``
+
+        Chain A's loss terms depend on nothing chain B computes, so its backward -- a third of the generators' backward work -- runs
+        under chain B's forward.  Each network's three passes keep the reference's order (A2B: real_A, real_B, fake_A; B2A: real_A,
+        fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence.  Returns (o, L, root):
+        ``root`` is what is left to back-propagate (chain B's terms)."""
+        G_A2B, G_B2A, w = self.netG_A2B, self.netG_B2A, self.w
+        ones, _ = self.targets(real_A.shape[0])
+        main = torch.cuda.current_stream(self.device)
+        X, I, side = self._aba, self._idt, self._side
+        cA, cB = self._branch
+        o, L = {}, {}
+        hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the main stream
+        hfB, lfB = ops.freq_split(real_B, 5, 14)
+        ev_in = main.record_event()
+        for t in (hfA, lfA, hfB, lfB, real_A, real_B):
+            t.record_stream(X)
+            t.record_stream(I)
+
+        def identity(net, first, second, real, key, after):
+            I.wait_event(ev_in)
+            if after is not None:
+                I.wait_event(after)
+            with torch.cuda.stream(I):
+                _, _, o[key] = net(first, second)
+                ev = I.record_event()
+                term = ops.l1_loss(real, o[key], w["beta2"])
+                ops.wgrad_stream = side
+                try:
+                    term.backward()
+                finally:
+                    ops.wgrad_stream = None
+            o[key].record_stream(main)
+            term.record_stream(main)
+            return ev, term.detach()
+
+        def critic(net, fake, st, src):
+            st.wait_stream(src)
+            fake.record_stream(st)
+            with torch.cuda.stream(st):
+                pred = net(fake)
+            return pred, st.record_event()
+
+        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                   # B2A pass 1
+        X.wait_event(ev_in)
+        with torch.cuda.stream(X):
+            _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                  # A2B pass 1
+            ev_a2b_1 = X.record_event()
+            o["hf_feature_A"] = hf_feature_A.detach()
+            pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, X)
+            hf, lf = ops.freq_split(o["fake_B"], 5, 14)
+            X.wait_event(ev_idt_A)
+            o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                # B2A pass 2
+            ev_b2a_2 = X.record_event()
+            X.wait_event(ev_pred_B)
+            pred_B.record_stream(X)
+            L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
+            L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
+            ops.wgrad_stream = side
+            try:
+                (L["loss_GAN_A2B"] + L["loss_cycle_ABA"]).backward()
+            finally:
+                ops.wgrad_stream = None
+        main.wait_event(ev_b2a_2)
+        hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                      # B2A pass 3
+        o["hf_feature_B"] = hf_feature_B.detach()
+        pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, main)
+        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2
+        hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        main.wait_event(ev_idt_B)
+        _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                    # A2B pass 3
+        main.wait_event(ev_pred_A)
+        pred_A.record_stream(main)
+        L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
+        L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
+            ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
+        root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+        for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
+            L[k].record_stream(main)
+            L[k] = L[k].detach()
+        for k in ("fake_B", "hf_feature_A", "hf_feature_recovered_A", "recovered_A"):
+            o[k].record_stream(main)
+        L["loss_idt"] = idt_A + idt_B
+        o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
+        L["loss_G"] = root.detach() + L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"]
+        return o, L, root
+
     def generator_loss(self, o, real_A, real_B):
         """train.py:221-236 (+ the opt-in SSIM term of the commented line train.py:234 and a wavelet-HF L1 term).  ``L["_root"]`` is
         what remains to be back-propagated (everything, unless ``forward_generators`` already did the identity terms)."""
@@ -361,10 +454,16 @@ class TrainStep:
         set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
         self.opt_G.zero_grad()                                              # train.py:220 (before the first backward of a generator term)
         multi = streams and packed
-        o = self.forward_generators(real_A, real_B, self._branch if multi else None, (self._idt, self._side) if multi else None)
-        # (2) generators, train.py:218-239
-        L = self.generator_loss(o, real_A, real_B)
-        root = L.pop("_root")
+        # (ending a hipGraph capture that holds the two-chain pattern crashes inside hipStreamEndCapture on ROCm 7.2: the captured
+        # step keeps the single-chain schedule)
+        two_chains = multi and not self.ssim_weight and not self.whf_weight and not torch.cuda.is_current_stream_capturing()
+        if two_chains:
+            o, L, root = self._generators_two_chains(real_A, real_B)
+        else:
+            o = self.forward_generators(real_A, real_B, self._branch if multi else None, (self._idt, self._side) if multi else None)
+            # (2) generators, train.py:218-239
+            L = self.generator_loss(o, real_A, real_B)
+            root = L.pop("_root")
         side_G, side_D = (self._side, self._side_D) if streams else (None, None)
         branches = self._branch if streams else (None, None)
         # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
@@ -379,8 +478,11 @@ class TrainStep:
                 root.backward()
             finally:
                 ops.wgrad_stream = None
-                if multi:                        # the identity terms' backward ran on their own stream (BatchNorm affine gradients there)
+                if multi:                        # the identity terms' / chain A's backward ran on their own streams (BatchNorm affine gradients there)
                     torch.cuda.current_stream(self.device).wait_stream(self._idt)
+                    torch.cuda.current_stream(self.device).wait_stream(self._aba)
+                    for st in self._branch:      # ... and the frozen discriminator passes' input gradients on the branch streams
+                        torch.cuda.current_stream(self.device).wait_stream(st)
                 ops.join_wgrad_stream(side_G)
             hyper_G = None if _static is None else _static["hyper_G"]
             g_update_aside = self.distributed and streams
