@@ -279,7 +279,7 @@ class TrainStep:
         return o
 
     def _generators_two_chains(self, real_A, real_B):
-        """The generator phase (train.py:173-236) as two chains on two streams, for the plain loss (no SSIM / wavelet terms):
+        """The generator phase (train.py:173-236) as two chains on two streams:
 
             chain A (stream ``_aba``):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
             chain B (main stream)    :  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
@@ -341,9 +341,13 @@ class TrainStep:
             pred_B.record_stream(X)
             L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
             L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
+            chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
+            extra_A = self._extension_terms(o["recovered_A"], real_A)
+            for k, v in extra_A.items():
+                chain_A = chain_A + v
             ops.wgrad_stream = side
             try:
-                (L["loss_GAN_A2B"] + L["loss_cycle_ABA"]).backward()
+                chain_A.backward()
             finally:
                 ops.wgrad_stream = None
         main.wait_event(ev_b2a_2)
@@ -360,6 +364,12 @@ class TrainStep:
         L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
             ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
         root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+        done = None
+        for k, v in self._extension_terms(o["recovered_B"], real_B).items():        # opt-in SSIM / wavelet-HF terms: one half per chain
+            root = root + v
+            extra_A[k].record_stream(main)
+            L[k] = v + extra_A[k].detach()
+            done = extra_A[k].detach() if done is None else done + extra_A[k].detach()
         for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
             L[k].record_stream(main)
             L[k] = L[k].detach()
@@ -368,7 +378,23 @@ class TrainStep:
         L["loss_idt"] = idt_A + idt_B
         o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
         L["loss_G"] = root.detach() + L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"]
+        if done is not None:
+            L["loss_G"] = L["loss_G"] + done
         return o, L, root
+
+    def _extension_terms(self, rec, real):
+        """One image pair's share of the opt-in terms of ``generator_loss`` (SSIM: train.py:234; wavelet-HF L1)."""
+        t = {}
+        if self.ssim_weight:
+            t["loss_ssim"] = self.ssim_weight * (1 - ops.ssim(rec, real))
+        if self.whf_weight:
+            acc = 0
+            _, yh_r = self.dwt_loss(rec)
+            _, yh_t = self.dwt_loss(real)
+            for a, b in zip(yh_r, yh_t):
+                acc = acc + ops.l1_loss(a, b, self.whf_weight)
+            t["loss_whf"] = acc
+        return t
 
     def generator_loss(self, o, real_A, real_B):
         """train.py:221-236 (+ the opt-in SSIM term of the commented line train.py:234 and a wavelet-HF L1 term).  ``L["_root"]`` is
@@ -456,7 +482,7 @@ class TrainStep:
         multi = streams and packed
         # (ending a hipGraph capture that holds the two-chain pattern crashes inside hipStreamEndCapture on ROCm 7.2: the captured
         # step keeps the single-chain schedule)
-        two_chains = multi and not self.ssim_weight and not self.whf_weight and not torch.cuda.is_current_stream_capturing()
+        two_chains = multi and not torch.cuda.is_current_stream_capturing()
         if two_chains:
             o, L, root = self._generators_two_chains(real_A, real_B)
         else:

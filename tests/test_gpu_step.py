@@ -158,6 +158,13 @@ def test_extension_terms_vs_oracle(fa, O):
     gn, go = ts.grad_norms(), S.grad_norms()
     for k in ("A2B", "B2A"):
         assert gn[k] == pytest.approx(go[k], rel=2e-3), k
+    # second step: the multi-stream schedule (the opt-in terms are split over the two generator chains)
+    a, b = O.synthetic_batch(1, 192, seed=4321)
+    L = ts.step(a.cuda(), b.cuda(), sync=True)
+    Lo = S.train_step(a, b)
+    _check_step(L, Lo, 1)
+    for k in ("loss_ssim", "loss_whf"):
+        assert L[k] == pytest.approx(Lo[k], rel=1e-3), (k, L[k], Lo[k])
 
 
 def test_inference_path_eval_mode(fa, O):
