@@ -31,6 +31,7 @@ def host_threads():
 def fa():
     import faoctasr
     faoctasr._lib.load()
+    faoctasr.TrainStep.overlap_min_pixels = 0      # the multi-stream schedule at every size (product default: from 2 x 256^2 pixels on)
     return faoctasr
 
 

@@ -28,6 +28,7 @@ def host_threads():
 def fa():
     import faoctasr
     faoctasr._lib.load()
+    faoctasr.TrainStep.overlap_min_pixels = 0      # the multi-stream schedule at every size (product default: from 2 x 256^2 pixels on)
     return faoctasr
 
 
@@ -313,3 +314,37 @@ def test_train_step_non_square_vs_oracle(fa, O):
             gn, go = ts.grad_norms(), S.grad_norms()
             for k in gn:
                 assert gn[k] == pytest.approx(go[k], rel=2e-3), k
+
+
+@pytest.mark.gpu
+def test_stream_schedule_equals_single_stream(fa, O):
+    """The multi-stream schedule changes when kernels run, not what they compute: three steps of it against three
+    steps on one stream, same state and inputs.  Step-0 losses agree to 2e-5 (run-to-run noise); afterwards both follow the same
+    trajectory within the step>=1 policy of ``_check_step``; the small-batch default (one stream below 2 x 256^2 pixels) is the
+    single-stream path itself."""
+    runs = {}
+    for overlap in (True, False):
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], overlap_wgrad=overlap)
+        out = []
+        for step in range(3):
+            a, b = O.synthetic_batch(2, 192, seed=99 + step)
+            out.append(ts.step(a.cuda(), b.cuda(), sync=True))
+        runs[overlap] = out
+    for k, v in runs[False][0].items():
+        assert runs[True][0][k] == pytest.approx(v, rel=2e-5, abs=1e-7), k
+    for step in (1, 2):
+        _check_step(runs[True][step], runs[False][step], step)
+    default = fa.TrainStep.overlap_min_pixels
+    try:
+        fa.TrainStep.overlap_min_pixels = 2 * 256 * 256
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"])
+        a, b = O.synthetic_batch(2, 192, seed=99)
+        for _ in range(2):
+            ts.step(a.cuda(), b.cuda())
+        assert ts._pack_plan is not None          # batched packs are independent of the stream schedule
+    finally:
+        fa.TrainStep.overlap_min_pixels = default
