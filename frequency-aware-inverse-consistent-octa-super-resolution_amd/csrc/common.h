@@ -13,6 +13,7 @@ int fail(int code, const char* fmt, ...);
 enum Route { ROUTE_NONE = 0, ROUTE_GATHER_FLAT = 1, ROUTE_PATCH = 2, ROUTE_WINOGRAD = 3, ROUTE_BF16X3 = 4, ROUTE_M1_FWD = 5, ROUTE_NARROW = 6,
              ROUTE_WGRAD_FLAT = 11, ROUTE_WGRAD_PATCH = 12, ROUTE_WGRAD_S1 = 13, ROUTE_M1_WGRAD = 14, ROUTE_WGRAD_X3 = 15, ROUTE_STEM_DGRAD = 7, ROUTE_STEM_WGRAD = 16 };
 void set_route(int r);
+extern thread_local int g_no_split_k;
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute is issued once per (kernel, size step), not
 // per launch: the only process-wide state of the library is this grow-only record of attributes already set

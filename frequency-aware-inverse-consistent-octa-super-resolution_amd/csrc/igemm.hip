@@ -415,9 +415,7 @@ static int launch_gather(const float* x, const float* w, const float* bias, floa
             if (ksplit > nchunks / 4) ksplit = nchunks / 4;
             if (ksplit < 1) ksplit = 1;
         }
-#ifdef FAOCTASR_NO_SPLITK
-        ksplit = 1;
-#endif
+        if (g_no_split_k) ksplit = 1;
         if (ksplit > 1) {
             hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s);
             if (e != hipSuccess) return fail(FAOCTASR_EHIP, "memset y: %s", hipGetErrorString(e));
@@ -458,6 +456,9 @@ static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || 
 // sink->blocks stays 0 when the call's route uses no packed image.
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
                       int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr) {
+    // FAOCTASR_CONV_NO_SPLIT_K: a reproducible result (one block owns the whole reduction of an output element) for this call
+    struct Scope { int prev; Scope(int v) : prev(g_no_split_k) { g_no_split_k = v; } ~Scope() { g_no_split_k = prev; } } scope((precision & FAOCTASR_CONV_NO_SPLIT_K) ? 1 : 0);
+    precision &= 0xff;
     if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     if (wpack && wpack_state && precision == 2) {
         const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
@@ -526,7 +527,7 @@ long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stri
         default: return fail(FAOCTASR_EINVAL, "conv_wpack_floats: unknown kind %d", kind);
     }
     if (rc) return rc;
-    return wpack_floats(g, precision);
+    return wpack_floats(g, precision & 0xff);
 }
 
 // The packing job a wpack_state == 1 call of the matching entry point would launch, written to a host slot of
@@ -609,6 +610,7 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
                           int stride, int pad, int reflect, int accumulate, int precision, faoctasr_stream_t stream) {
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
+    precision &= 0xff;             // the weight gradients have no split-K policy to switch: they always accumulate with atomics
     if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");

@@ -458,6 +458,7 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
         if (ksplit > ngroups / 2) ksplit = ngroups / 2;
         ksplit = ksplit < 1 ? 1 : ksplit;
     }
+    if (g_no_split_k) ksplit = 1;
     if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
         return fail(FAOCTASR_EHIP, "memset y failed");
     const size_t lds = sp_lds(g, NI, g.SI);

@@ -233,9 +233,7 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
         if (ksplit > minchunks / 4) ksplit = minchunks / 4;
         if (ksplit < 1) ksplit = 1;
     }
-#ifdef FAOCTASR_NO_SPLITK
-    ksplit = 1;
-#endif
+    if (g_no_split_k) ksplit = 1;
     if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
         return fail(FAOCTASR_EHIP, "memset y failed");
     const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(g.nphase * ksplit));

@@ -556,9 +556,7 @@ static int launch_cfg(const float* x, const float* wp, const float* bias, float*
 // quarter-K blocks), and 680 blocks (the 7x7 input gradient on its 134x134 padded grid) want ks = 3 (3.98 rounds of thirds =
 // 1.33 instead of 2).  Each split adds one atomic pass over the output, priced as ~30 K-steps per split relative to the K depth.
 static int pick_ksplit(const PatchGeom& g, long blocks, int act) {
-#ifdef FAOCTASR_NO_SPLITK      // diagnostic build (tools/run_to_run.py): no split-K atomics in the gather kernels -> bit-reproducible forward
-    return 1;
-#endif
+    if (g_no_split_k) return 1;        // FAOCTASR_CONV_NO_SPLIT_K: no atomics, bit-reproducible output
     if (act != FAOCTASR_ACT_NONE || blocks <= 0) return 1;
     int minchunks = 1 << 30, kdepth = 1 << 30;
     for (int p = 0; p < g.nphase; ++p) {

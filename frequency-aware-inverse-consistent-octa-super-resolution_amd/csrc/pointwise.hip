@@ -19,6 +19,7 @@ int fail(int code, const char* fmt, ...) {
 }
 
 thread_local int g_route = 0;
+thread_local int g_no_split_k = 0;         // set by run_gather for the duration of a call made with FAOCTASR_CONV_NO_SPLIT_K
 void set_route(int r) { g_route = r; }
 int get_route() { return g_route; }
 

@@ -45,6 +45,10 @@ use_wpack = True
 #: 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate)
 conv_precision = 0
 PRECISIONS = {"f32": 0, "f32_direct": 1, "bf16x3": 2}
+#: FAOCTASR_CONV_NO_SPLIT_K (include/faoctasr.h) on every FORWARD convolution: no fp32 atomics in the forward pass, so its
+#: activations -- and with them every ReLU / LeakyReLU mask the backward uses -- are bit-reproducible from run to run
+reproducible_forward = False
+NO_SPLIT_K = 0x100
 _wpack_cache = {}
 #: calls that had to pack inside the convolution call itself (state 1); a ``PackPlan`` owner watches it to learn about new images
 pack_misses = 0
@@ -188,7 +192,7 @@ class _Conv2d(Function):
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
-             conv_precision, stream_ptr())
+             conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, reflect, act, slope)
@@ -255,7 +259,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
-             ptr(wp), wst, conv_precision, stream_ptr())
+             ptr(wp), wst, conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, out_pad, act, slope)

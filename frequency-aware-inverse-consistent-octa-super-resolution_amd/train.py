@@ -146,12 +146,17 @@ class TrainStep:
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
-                 process_group=None, distributed=None, init=True, precision="f32", overlap_wgrad=True):
+                 process_group=None, distributed=None, init=True, precision="f32", overlap_wgrad=True,
+                 reproducible_forward=False):
         """``precision``: "f32" = exact fp32 MFMA contraction (default); "bf16x3" = forward / input-gradient convolutions on
         the bf16 matrix cores with hi/lo-split operands (fp32-parity: step-0 losses within ~1e-4; weight gradients stay fp32)."""
         if precision not in ops.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISIONS))
         self.precision = precision
+        #: forward convolutions without split-K atomics (FAOCTASR_CONV_NO_SPLIT_K): the forward pass, the losses and every activation
+        #: mask are then bit-reproducible and two runs differ only by the summation order of the gradient atomics (~2e-6 relative on
+        #: the arenas instead of up to 5e-3, DESIGN.md section 2); ~5 % slower at batch 8 (narrow discriminator maps under-fill the chip)
+        self.reproducible_forward = bool(reproducible_forward)
         dev = torch.device(device)
         made = netG_A2B is None
         self.netG_A2B = (netG_A2B or NetworkA2B()).to(dev)            # train.py:73-76
@@ -475,6 +480,7 @@ class TrainStep:
         backward produces -- so once every packed-weight image is current it is enqueued on two branch streams BEFORE
         ``loss_G.backward()`` and its narrow-map, low-occupancy kernels run under the generators' large ones."""
         ops.conv_precision = ops.PRECISIONS[self.precision]
+        ops.reproducible_forward = self.reproducible_forward
         misses = ops.pack_misses
         packed = self._pack_plan is not None and self._pack_plan.run()     # every packed-weight image of the step in one launch
         if not packed:
@@ -543,6 +549,7 @@ class TrainStep:
             # some convolution packed its own weights: first step, new batch size or precision -> (re)collect the images this step used
             self._pack_plan = ops.PackPlan(self.opt_G.params + self.opt_D.params, ops.conv_precision)
         ops.conv_precision = 0
+        ops.reproducible_forward = False
         out = {k: v.detach() for k, v in L.items()}
         if sync:
             out = {k: float(v) for k, v in out.items()}

@@ -49,7 +49,11 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
  * `precision`: 0 = exact fp32 on v_mfma_f32_32x32x2_f32; 2 = "bf16x3": operands split hi/lo into bf16, three
  * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (fp32-parity, ~5x the MFMA rate; needs a wpack buffer and
  * C >= 16, width >= 24 -- other shapes silently use the fp32 kernels).  The packed image depends on `precision` and on
- * whether the map is wide enough for the split kernel, so keep one buffer per (weights, precision, input size).  */
+ * whether the map is wide enough for the split kernel, so keep one buffer per (weights, precision, input size).
+ * OR-ing FAOCTASR_CONV_NO_SPLIT_K into `precision` of a gather call keeps the whole reduction of an output element in one
+ * block: no fp32 atomics, a bit-reproducible result, at the price of under-filled grids on narrow maps (the kernels otherwise
+ * split K across blocks when a layer has fewer blocks than the chip has CUs).                                          */
+#define FAOCTASR_CONV_NO_SPLIT_K 0x100
 long faoctasr_conv_wpack_floats(int kind, int C, int M, int KH, int KW, int stride, int pad, int precision);
 /* Batched packing: all packed-weight images of a step in ONE launch (csrc/conv_pack.hip).  Each convolution call of
  * train.py:166-269 re-reads weights the optimizer has just changed (train.py:239,268), i.e. ~240 images per step;

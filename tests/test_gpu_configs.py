@@ -108,7 +108,7 @@ def test_config4_rccl_shard_b32_and_run_to_run_spread(fa, O, rccl_world1):
     fp32 atomics, so a forward activation moves by ~1e-7 from run to run, and the few that sit within that distance of a
     LeakyReLU / ReLU kink change side, which moves the gradients by a DISCRETE amount (tools/run_to_run.py at this batch: the
     generator arena is either 2e-6 or 3.7e-4 away from another run, the discriminator arena takes the values 6e-7 .. 1.8e-4; with
-    the split-K paths compiled out, -DFAOCTASR_NO_SPLITK, every run agrees to 5e-7, and a repeated backward of ONE forward graph
+    FAOCTASR_CONV_NO_SPLIT_K on every gather call every run agrees to 5e-7, and a repeated backward of ONE forward graph
     to 2e-6: tools/probe/backward_repeat.py).  What is asserted is a bound on that spread -- step-0 losses 2e-5 relative, gradient
     arenas 1e-3 relative L2 -- for the run-to-run pair, and the SAME bound for the RCCL step, i.e. the exchange adds nothing."""
     B, H = 32, 256

@@ -348,3 +348,29 @@ def test_stream_schedule_equals_single_stream(fa, O):
         assert ts._pack_plan is not None          # batched packs are independent of the stream schedule
     finally:
         fa.TrainStep.overlap_min_pixels = default
+
+
+@pytest.mark.gpu
+def test_reproducible_forward_mode(fa, O):
+    """``TrainStep(reproducible_forward=True)``: forward convolutions carry FAOCTASR_CONV_NO_SPLIT_K, so two runs from the same
+    state produce bit-identical forward tensors and losses, and gradient arenas that differ only by atomic summation order
+    (<= 1e-5 relative L2; the default mode shows up to 5e-3 at batch 8 through LeakyReLU / ReLU kink flips).
+    The mode changes no value beyond that: its step-0 losses equal the default mode's to 2e-5."""
+    a, b = O.synthetic_batch(4, 256, seed=31)
+    a, b = a.cuda(), b.cuda()
+    runs = []
+    for mode in (True, True, False):
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], reproducible_forward=mode)
+        L = ts.step(a, b, sync=True, keep=True)
+        runs.append((L, ts.opt_G.grad.clone(), ts.opt_D.grad.clone()))
+    (L0, g0, d0), (L1, g1, d1), (L2, _, _) = runs
+    for k in ("fake_A", "fake_B", "recovered_A", "recovered_B", "idt_A", "idt_B"):
+        assert torch.equal(L0["tensors"][k], L1["tensors"][k]), k
+    for k, v in L0.items():
+        if k != "tensors":
+            assert v == L1[k], k                                          # bit-identical losses, discriminator losses included
+            assert v == pytest.approx(L2[k], rel=2e-5, abs=1e-7), k
+    for x, y in ((g0, g1), (d0, d1)):
+        assert float((x.double() - y.double()).norm() / y.double().norm()) < 1e-5

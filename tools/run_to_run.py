@@ -1,6 +1,6 @@
 """Run-to-run spread of one train step from identical state and inputs (the step is not bit-reproducible: fp32 atomics), with the
 weight gradients / discriminator branches on side streams and without.  A race would show as a spread far above the single-stream one.
-usage: python tools/run_to_run.py [batch] [size] [pairs]"""
+usage: python tools/run_to_run.py [batch] [size] [pairs] [only] [--reproducible-forward]"""
 import os
 import random
 import sys
@@ -15,10 +15,13 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 PAIRS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 
 
+REPRO = "--reproducible-forward" in sys.argv
+
+
 def one(overlap, a, b):
     torch.manual_seed(0)
     random.seed(1234)
-    ts = faoctasr.TrainStep(device="cuda", overlap_wgrad=overlap)
+    ts = faoctasr.TrainStep(device="cuda", overlap_wgrad=overlap, reproducible_forward=REPRO)
     L = ts.step(a, b, sync=True)
     out = (L, ts.opt_G.grad.clone(), ts.opt_D.grad.clone(), [(a.names, a.offsets, [p.numel() for p in a.params]) for a in (ts.opt_G, ts.opt_D)])
     del ts
