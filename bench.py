@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
     ap.add_argument("--graph-only", action="store_true", help="(internal) measure only the hipGraph-captured step and print it")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="data-parallel runs: keep the gradient all-reduces on the main stream")
+    ap.add_argument("--layout", default=None, help="(experiments) TrainStep.stream_layout, e.g. 012301")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
     ap.add_argument("--force-launch", action="store_true", help="take the self-launch path (torch.distributed.run children) even for one GPU")
     ap.add_argument("--ddp-graph", action="store_true", help="data-parallel runs: also measure the hipGraph-captured step (RCCL inside the capture)")
@@ -256,7 +258,10 @@ def main():
     # distributed: TrainStep creates the RCCL communicator behind the C ABI and broadcasts rank 0's arenas / BN buffers
     if args.graph_only:
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
+    if args.layout:
+        faoctasr.TrainStep.stream_layout = args.layout
     ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision, overlap_wgrad=not args.no_overlap)
+    ts.overlap_exchange = not args.no_overlap_exchange
     B, H = args.batch, args.size
     real_A, real_B = make_batch(B, H, device, rank)
 

@@ -154,7 +154,9 @@ def _enqueue_wgrad(fn, *operands):
     if side is None:
         fn(stream_ptr())
         return
-    side.wait_stream(torch.cuda.current_stream())
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream != side.cuda_stream:
+        side.wait_stream(cur)
     with torch.cuda.stream(side):
         fn(side.cuda_stream)
     _wgrad_keep.setdefault(side.cuda_stream, []).append(operands)

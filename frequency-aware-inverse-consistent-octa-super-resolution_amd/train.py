@@ -140,7 +140,22 @@ class ParamArena:
         return [lr, b1, b2, f32(self.eps), f32(self.weight_decay), f32(lr / bc1), f32(1.0 / math.sqrt(bc2)), f32(grad_scale)]
 
 
+def _wait(waiter, on):
+    """``waiter.wait_stream(on)`` unless both roles are the same stream (``TrainStep.stream_layout``): a stream waiting on its own
+    event is a no-op eagerly, but ending a hipGraph capture that recorded one crashes inside the ROCm 7.2 runtime."""
+    if waiter.cuda_stream != on.cuda_stream:
+        waiter.wait_stream(on)
+
+
 class TrainStep:
+    #: which of the schedule's six roles share a HIP stream (see __init__).  The runtime multiplexes streams onto 4 hardware queues
+    #: in creation order, and MORE concurrency is not better (one stream per role on 8 queues: 116.3 ms; on the default 4 queues the
+    #: outcome depended on which roles happened to share a queue: 110.6 ms plain, 116.4 once RCCL's own streams had shifted the order).
+    #: Three streams beside the caller's, with the sharing chosen: all weight gradients | discriminator A + identity passes |
+    #: discriminator B + generator chain A  ->  109.4 ms plain, 112.1 ms with a communicator (bench.py --layout explores others)
+    stream_layout = "001212"
+    #: data-parallel runs: gradient all-reduces on side streams under the remaining backward work (False: on the main stream, in place)
+    overlap_exchange = True
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
     overlap_min_pixels = 2 * 256 * 256
 
@@ -181,13 +196,15 @@ class TrainStep:
         self.comm = None
         #: second HIP stream for the weight gradients (ops.wgrad_stream); ``overlap_wgrad=False`` keeps everything on one stream
         self.overlap_wgrad = bool(overlap_wgrad)
-        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._side_D = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        #: the two discriminators' updates (train.py:242-269) share nothing: each runs forward and backward on its own stream, so
-        #: their small deep-layer kernels (4x4 .. 32x32 maps, far fewer blocks than CUs) fill the chip together
-        self._branch = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if dev.type == "cuda" else None
-        self._idt = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self._aba = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # roles -> streams (``stream_layout``: roles with the same digit share a stream).  Roles: generators' weight gradients,
+        # discriminators' weight gradients, discriminator A's branch (frozen pass + update phase), discriminator B's branch, identity
+        # passes, generator chain A.
+        self._side = self._side_D = self._idt = self._aba = self._branch = None
+        if dev.type == "cuda":
+            made = {}
+            roles = [made.setdefault(ch, torch.cuda.Stream(device=dev)) for ch in self.stream_layout]
+            self._side, self._side_D, bA, bB, self._idt, self._aba = roles
+            self._branch = (bA, bB)
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
         if self.distributed:
             if dev.type != "cuda":
@@ -328,7 +345,7 @@ class TrainStep:
             return ev, term.detach()
 
         def critic(net, fake, st, src):
-            st.wait_stream(src)
+            _wait(st, src)
             fake.record_stream(st)
             with torch.cuda.stream(st):
                 pred = net(fake)
@@ -506,10 +523,18 @@ class TrainStep:
         # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
         # needs them all written up front (the plan), i.e. not the first step / a step after the plan was dropped
         early_D = streams and packed
-        held = None
+        held, d_reduced = None, False
         try:
             if early_D:
                 held = self._discriminator_phase(L, o, real_A, real_B, _static, branches, side_D)
+                if self.distributed and self.overlap_exchange:
+                    # the discriminators' gradients are complete once their branches and their weight-gradient stream have drained:
+                    # their exchange (the larger arena) starts here and runs under the generators' backward
+                    for st in branches:
+                        _wait(side_D, st)
+                    with torch.cuda.stream(side_D):
+                        self.opt_D.all_reduce(self.group, self.comm)
+                    d_reduced = True
             ops.wgrad_stream = side_G
             try:
                 root.backward()
@@ -522,11 +547,13 @@ class TrainStep:
                         torch.cuda.current_stream(self.device).wait_stream(st)
                 ops.join_wgrad_stream(side_G)
             hyper_G = None if _static is None else _static["hyper_G"]
-            g_update_aside = self.distributed and streams
+            g_update_aside = self.distributed and streams and self.overlap_exchange
             if g_update_aside:
                 # the generators' gradient exchange and AdamW touch nothing the discriminator phase reads: they run on the side
                 # stream under it and are joined before the discriminators' update
                 side_G.wait_stream(torch.cuda.current_stream(self.device))
+                if d_reduced:                    # one collective at a time on the communicator, in the same order on every rank
+                    _wait(side_G, side_D)
                 with torch.cuda.stream(side_G):
                     self.opt_G.all_reduce(self.group, self.comm)
                     self.opt_G.step(1.0 / self.world, hyper_G)
@@ -542,7 +569,7 @@ class TrainStep:
                 self._join_discriminator_phase(branches, side_D)
                 ops.join_wgrad_stream(side_G)
         del held
-        if self.distributed:
+        if self.distributed and not d_reduced:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
         if ops.pack_misses != misses and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
