@@ -284,11 +284,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_G = float(L["loss_G"])
+    # host time to ENQUEUE a step (no device synchronisation inside the loop): how far ahead of the GPU the host runs
+    th = time.perf_counter()
+    for _ in range(5):
+        ts.step(real_A, real_B)
+    host_ms = 1e3 * (time.perf_counter() - th) / 5
+    barrier()
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
     roof = None
-    extra = {}
+    extra = {"host_enqueue_ms_per_step": round(host_ms, 2)}
     if not args.no_roofline:
         # every rank runs these extra steps (they contain the gradient all-reduces); only rank 0 brackets its launches
         timer = LaunchTimer(GATHER + WGRAD) if rank == 0 else None
