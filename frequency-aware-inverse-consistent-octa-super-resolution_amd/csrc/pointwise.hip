@@ -466,7 +466,7 @@ using namespace faoctasr;
 
 extern "C" {
 
-int faoctasr_version(void) { return 200; }
+int faoctasr_version(void) { return 210; }
 const char* faoctasr_last_error(void) { return err_buf(); }
 int faoctasr_last_route(void) { return faoctasr::get_route(); }
 

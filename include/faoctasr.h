@@ -27,9 +27,9 @@ enum { FAOCTASR_OK = 0, FAOCTASR_EINVAL = -1, FAOCTASR_EUNSUPPORTED = -2, FAOCTA
 int faoctasr_version(void);
 const char* faoctasr_last_error(void);
 /* diagnostics (bench.py's per-family roofline): the kernel family the calling thread's last convolution-type call went to:
- * 1 flat implicit GEMM, 2 LDS-patch implicit GEMM, 3 Winograd F(2x2,3x3), 4 bf16x3 split, 5 M=1 head (VALU), 6 narrow-map GEMM;
- * 11 flat weight gradient, 12 LDS-patch weight gradient, 13 stride-1 weight gradient (wgrad_s1), 14 M=1 weight gradient,
- * 15 bf16x3 weight gradient (wgrad_x3)                                                                                      */
+ * 1 flat implicit GEMM, 2 LDS-patch implicit GEMM, 3 Winograd F(2x2,3x3), 4 bf16x3 split, 5 M=1 head (VALU), 6 narrow-map GEMM,
+ * 7 stem input gradient (1..4 input channels, VALU); 11 flat weight gradient, 12 LDS-patch weight gradient, 13 stride-1 / 4x4
+ * stride-2 weight gradient (wgrad_s1), 14 M=1 weight gradient, 15 bf16x3 weight gradient (wgrad_x3), 16 stem weight gradient (VALU) */
 int faoctasr_last_route(void);
 
 /* ---- convolution family (implicit GEMM on f32 MFMA) --------------------------------------
