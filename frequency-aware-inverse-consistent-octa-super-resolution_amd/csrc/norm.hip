@@ -73,7 +73,17 @@ __device__ __forceinline__ void publish_stats(const RowStats& s, int r, long L, 
 }
 
 // ---- streaming kernels (HW % 4 == 0) ------------------------------------------------------------------------------------------
-constexpr int NU = 4;                                                  // independent 16-byte loads per operand and thread
+// Independent 16-byte loads per operand and thread.  2, not 4: alone the kernels run as fast either way (more waves fit), but at 2 every
+// streaming kernel stays within 48 VGPRs -- what is left on a SIMD beside two 232-VGPR Winograd waves -- so that BatchNorm passes of one
+// generator chain co-reside with the other chain's convolutions (step 109.4 -> 108.8 ms)
+#ifndef BN_SMALL_FWD
+#define BN_SMALL_FWD 16384      // rows up to this length run as ONE kernel per direction with the row in registers (66 / 122 / 234 VGPRs)
+#define BN_SMALL_BWD 8192
+#endif
+#ifndef BN_NU
+#define BN_NU 2
+#endif
+constexpr int NU = BN_NU;
 
 __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int R, int HW, long L, int S,
                                                          long per) {
@@ -522,7 +532,7 @@ static int norm_fwd(const float* x, const float* gamma, const float* beta, const
     if (!x || !y || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_fwd: null pointer");
     if (NI <= 0 || R <= 0 || HW <= 0) return fail(FAOCTASR_EINVAL, "norm_fwd: bad shape");
     const long L = (long)NI * HW;
-    if ((HW & 3) == 0 && L <= 16384) {
+    if ((HW & 3) == 0 && L <= BN_SMALL_FWD) {
         auto go = [&](auto k) {
             hipLaunchKernelGGL(k, dim3(R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar, R, Cg, HW, L, eps,
                                momentum, act, slope);
@@ -557,7 +567,7 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
         if (dgamma) (void)hipMemsetAsync(dgamma, 0, sizeof(float) * Cg, st);
         if (dbeta) (void)hipMemsetAsync(dbeta, 0, sizeof(float) * Cg, st);
     }
-    if ((HW & 3) == 0 && L <= 8192) {
+    if ((HW & 3) == 0 && L <= BN_SMALL_BWD) {
         auto go = [&](auto k) {
             hipLaunchKernelGGL(k, dim3(R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, dres, R, Cg, HW, L,
                                act, slope, accumulate);
@@ -575,7 +585,7 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
                                HW, L, S, act, slope, per, accumulate);
         };
         if (y && act != FAOCTASR_ACT_NONE) go(norm_bwd_reduce_kernel<true, 2>, norm_bwd_dx_kernel<true, 2>);
-        else go(norm_bwd_reduce_kernel<false, 4>, norm_bwd_dx_kernel<false, 4>);
+        else go(norm_bwd_reduce_kernel<false, BN_NU>, norm_bwd_dx_kernel<false, BN_NU>);
     } else {
         hipLaunchKernelGGL(norm_bwd_reduce_generic_kernel, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, ws, R,
                            Cg, HW, L, S, act, slope, per);
