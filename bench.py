@@ -285,16 +285,18 @@ def main():
         elapsed = float(t)
     loss_G = float(L["loss_G"])
     # host time to ENQUEUE a step (no device synchronisation inside the loop): how far ahead of the GPU the host runs
-    th = time.perf_counter()
-    for _ in range(5):
-        ts.step(real_A, real_B)
-    host_ms = 1e3 * (time.perf_counter() - th) / 5
-    barrier()
+    host_ms = None
+    if args.steps >= 5:                       # (short runs are the rocprofv3 --pmc passes: every extra dispatch is recorded there)
+        th = time.perf_counter()
+        for _ in range(5):
+            ts.step(real_A, real_B)
+        host_ms = 1e3 * (time.perf_counter() - th) / 5
+        barrier()
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
     roof = None
-    extra = {"host_enqueue_ms_per_step": round(host_ms, 2)}
+    extra = {"host_enqueue_ms_per_step": None if host_ms is None else round(host_ms, 2)}
     if not args.no_roofline:
         # every rank runs these extra steps (they contain the gradient all-reduces); only rank 0 brackets its launches
         timer = LaunchTimer(GATHER + WGRAD) if rank == 0 else None
