@@ -259,7 +259,7 @@ def main():
     if args.graph_only:
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     if args.layout:
-        faoctasr.TrainStep.stream_layout = args.layout
+        faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = args.layout
     ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision, overlap_wgrad=not args.no_overlap)
     ts.overlap_exchange = not args.no_overlap_exchange
     B, H = args.batch, args.size

@@ -154,6 +154,9 @@ class TrainStep:
     #: Three streams beside the caller's, with the sharing chosen: all weight gradients | discriminator A + identity passes |
     #: discriminator B + generator chain A  ->  109.4 ms plain, 112.1 ms with a communicator (bench.py --layout explores others)
     stream_layout = "001212"
+    #: ... and with a communicator, whose own streams shift the stream -> hardware-queue assignment: generator chain A on a stream of
+    #: its own (111.5 -> 109.4 ms at world 1, three runs each; without a communicator this layout costs 112.9 ms)
+    stream_layout_comm = "001232"
     #: data-parallel runs: gradient all-reduces on side streams under the remaining backward work (False: on the main stream, in place)
     overlap_exchange = True
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
@@ -202,7 +205,8 @@ class TrainStep:
         self._side = self._side_D = self._idt = self._aba = self._branch = None
         if dev.type == "cuda":
             made = {}
-            roles = [made.setdefault(ch, torch.cuda.Stream(device=dev)) for ch in self.stream_layout]
+            layout = self.stream_layout_comm if self.distributed else self.stream_layout
+            roles = [made.setdefault(ch, torch.cuda.Stream(device=dev)) for ch in layout]
             self._side, self._side_D, bA, bB, self._idt, self._aba = roles
             self._branch = (bA, bB)
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
