@@ -31,6 +31,22 @@ for s in range(len(bounds) - 1):
     queues = sorted({r[3] for r in ks})
     print("step %d: wall %.2f ms, GPU busy (union) %.2f ms, sum of kernels %.2f ms (x%.2f), %d kernels, queues %s" % (
         s, (t1 - t0) / 1e6, busy / 1e6, tot / 1e6, tot / max(busy, 1), len(ks), queues))
+    # exposed time per family: the part of the step during which ONLY kernels of that family were running
+    fam = lambda n: ("norm" if "norm_" in n else "wgrad" if "wgrad" in n else "winograd" if "wino" in n else "patch/narrow/flat" if "igemm" in n
+                     else "pack" if "pack" in n else "aten/rocclr" if ("at::" in n or "rocclr" in n) else "other")
+    ev = []
+    for r in ks:
+        ev.append((r[0], 1, fam(r[2])))
+        ev.append((r[1], -1, fam(r[2])))
+    ev.sort()
+    active, excl, tprev = {}, {}, ev[0][0]
+    for t, d, f in ev:
+        live = [k for k, v in active.items() if v > 0]
+        if len(live) == 1:
+            excl[live[0]] = excl.get(live[0], 0) + (t - tprev)
+        active[f] = active.get(f, 0) + d
+        tprev = t
+    print("   exposed (sole running family) ms: " + ", ".join("%s %.2f" % (k, v / 1e6) for k, v in sorted(excl.items(), key=lambda kv: -kv[1])))
     gaps.sort(reverse=True)
     print("   idle total %.2f ms; largest gaps:" % (sum(g[0] for g in gaps) / 1e6))
     for g in gaps[:6]:
