@@ -151,10 +151,11 @@ class TrainStep:
     #: which of the schedule's six roles share a HIP stream (see __init__).  The runtime multiplexes streams onto 4 hardware queues
     #: in creation order, and MORE concurrency is not better (one stream per role on 8 queues: 116.3 ms; on the default 4 queues the
     #: outcome depended on which roles happened to share a queue: 110.6 ms plain, 116.4 once RCCL's own streams had shifted the order).
-    #: Four streams beside the caller's, with the sharing chosen: generators' weight gradients | discriminators' weight gradients +
-    #: identity passes | discriminator A + generator chain A | discriminator B  ->  108.7 ms plain (best of a sweep over ~90 partitions
-    #: of the roles, tools/layout_search.py; the runner-up "001212" with three streams: 109.1 ms)
-    stream_layout = "012312"
+    #: Three streams beside the caller's, with the sharing chosen: all weight gradients | discriminator A + identity passes |
+    #: discriminator B + generator chain A  ->  109.1 ms at batch 8.  A sweep over ~90 partitions of the roles (tools/layout_search.py)
+    #: found "012312" 0.4 ms faster at batch 8 but slower at batches 2, 16, 32 and 64 (45.1 vs 40.5 ms at batch 2): this one is the
+    #: most even across batch sizes
+    stream_layout = "001212"
     #: ... and with a communicator, whose own streams shift the stream -> hardware-queue assignment: generator chain A on a stream of
     #: its own (111.5 -> 109.4 ms at world 1, three runs each; without a communicator this layout costs 112.9 ms)
     stream_layout_comm = "001232"
