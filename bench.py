@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-captured step measurement")
     ap.add_argument("--graph-only", action="store_true", help="(internal) measure only the hipGraph-captured step and print it")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="data-parallel runs: keep the gradient all-reduces on the main stream")
+    ap.add_argument("--prio", default=None, help="(experiments) TrainStep.stream_priorities, comma separated")
     ap.add_argument("--min-pixels", type=int, default=None, help="(experiments) TrainStep.overlap_min_pixels")
     ap.add_argument("--layout", default=None, help="(experiments) TrainStep.stream_layout, e.g. 012301")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
@@ -261,6 +262,8 @@ def main():
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     if args.layout:
         faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = args.layout
+    if args.prio:
+        faoctasr.TrainStep.stream_priorities = [int(v) for v in args.prio.split(",")]
     if args.min_pixels is not None:
         faoctasr.TrainStep.overlap_min_pixels = args.min_pixels
     ts = faoctasr.TrainStep(device=device, distributed=distributed, precision=args.precision, overlap_wgrad=not args.no_overlap)

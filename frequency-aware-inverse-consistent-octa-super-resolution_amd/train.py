@@ -159,6 +159,8 @@ class TrainStep:
     #: ... and with a communicator, whose own streams shift the stream -> hardware-queue assignment: generator chain A on a stream of
     #: its own (111.5 -> 109.4 ms at world 1, three runs each; without a communicator this layout costs 112.9 ms)
     stream_layout_comm = "001232"
+    #: (experiments) one HIP stream priority per layout digit, e.g. [0, -1, -1]; None = all default
+    stream_priorities = None
     #: data-parallel runs: gradient all-reduces on side streams under the remaining backward work (False: on the main stream, in place)
     overlap_exchange = True
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
@@ -208,7 +210,8 @@ class TrainStep:
         if dev.type == "cuda":
             made = {}
             layout = self.stream_layout_comm if self.distributed else self.stream_layout
-            roles = [made.setdefault(ch, torch.cuda.Stream(device=dev)) for ch in layout]
+            prio = self.stream_priorities
+            roles = [made.setdefault(ch, torch.cuda.Stream(device=dev, priority=int(prio[int(ch)]) if prio else 0)) for ch in layout]
             self._side, self._side_D, bA, bB, self._idt, self._aba = roles
             self._branch = (bA, bB)
         self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
