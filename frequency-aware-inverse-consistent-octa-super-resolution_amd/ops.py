@@ -62,7 +62,7 @@ def invalidate_weight_cache():
 class _PackEntry:
     """One packed-weight image: the buffer, the gather call it belongs to (exactly the C call's arguments) and the weight
     version it holds."""
-    __slots__ = ("wref", "buf", "ver", "kind", "dims", "reflect", "out_pad", "precision", "touched")
+    __slots__ = ("wref", "buf", "ver", "kind", "dims", "reflect", "out_pad", "precision", "touched", "event", "ev_stream")
 
 
 def _ver(w):
@@ -71,11 +71,16 @@ def _ver(w):
 
 
 def _wpack(w, kind, dims, reflect=0, out_pad=0):
-    """(buffer, state) for the C ABI: state 1 = pack now, 2 = buffer already holds these weights.  ``dims`` =
-    (N, C, IH, IW, M, KH, KW, stride, pad) exactly as the gather call ``kind`` receives them."""
+    """(buffer, state, entry) for the C ABI: state 1 = pack now, 2 = buffer already holds these weights.  ``dims`` =
+    (N, C, IH, IW, M, KH, KW, stride, pad) exactly as the gather call ``kind`` receives them.
+
+    An image packed inside a convolution call (state 1) is ordered on that call's stream only.  The caller reports the launch with
+    ``_packed(entry, state)``, which records an event there; a later state-2 user on ANOTHER stream waits for that event here, so the
+    multi-stream schedule of ``TrainStep`` is safe on steps whose images are not covered by a ``PackPlan`` (first step, new batch
+    shape: the trailing partial batch of an epoch)."""
     global pack_misses
     if not use_wpack:
-        return None, 0
+        return None, 0, None
     key = (id(w), kind, conv_precision, dims, reflect, out_pad)
     ent = _wpack_cache.get(key)
     if ent is None or ent.wref() is not w:
@@ -85,18 +90,36 @@ def _wpack(w, kind, dims, reflect=0, out_pad=0):
         N, C, IH, IW, M, KH, KW, stride, pad = dims
         n = _lib.load().faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad, conv_precision)
         if n <= 0:
-            return None, 0
+            return None, 0, None
         ent = _PackEntry()
         ent.wref, ent.buf, ent.ver = weakref.ref(w), torch.empty(n, dtype=torch.float32, device=w.device), None
+        ent.event = ent.ev_stream = None
         ent.kind, ent.dims, ent.reflect, ent.out_pad, ent.precision = kind, dims, int(bool(reflect)), out_pad, conv_precision
         _wpack_cache[key] = ent
     ver = _ver(w)
     ent.touched = True
     if ent.ver == ver:
-        return ent.buf, 2
+        if ent.event is not None:
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != ent.ev_stream:         # packed inline on another stream: order this reader behind that launch
+                cur.wait_event(ent.event)
+        return ent.buf, 2, ent
     ent.ver = ver
     pack_misses += 1
-    return ent.buf, 1
+    return ent.buf, 1, ent
+
+
+def _packed(ent, state):
+    """After a convolution call that received ``state`` 1: remember where (stream) and when (event) the image was written."""
+    if state == 1:
+        cur = torch.cuda.current_stream()
+        ent.event, ent.ev_stream = cur.record_event(), cur.cuda_stream
+
+
+def clear_touched():
+    """Forget which images earlier steps used: the next ``PackPlan`` then holds exactly the images of the step run in between."""
+    for e in _wpack_cache.values():
+        e.touched = False
 
 
 class PackPlan:
@@ -134,7 +157,7 @@ class PackPlan:
             call("conv_pack_run", ptr(self.table), self.njobs, self.nblocks, stream_ptr())
         for e, w in live:
             e.ver = _ver(w)
-            e.touched = True
+            e.event = e.ev_stream = None      # written here, on the stream every role of the step forks from
         return True
 
 
@@ -165,7 +188,9 @@ def _enqueue_wgrad(fn, *operands):
 def join_wgrad_stream(side):
     """The current stream waits for everything enqueued on ``side``; the operands held for it are released."""
     if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != side.cuda_stream:
+            cur.wait_stream(side)
         _wgrad_keep.pop(side.cuda_stream, None)
 
 
@@ -192,9 +217,10 @@ class _Conv2d(Function):
             raise RuntimeError("Calculated padded input size per channel: (%d x %d). Kernel size: (%d x %d). "
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
+        wp, wst, ent = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
              conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
+        _packed(ent, wst)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, reflect, act, slope)
@@ -216,15 +242,17 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
-                wp, wst = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
+                wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
                      conv_precision, st)
+                _packed(ent, wst)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
             else:
                 dx = torch.empty_like(x)
-                wp, wst = _wpack(ctx.w_ref, 1, (N, C, IH, IW, M, KH, KW, stride, pad))
+                wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH, IW, M, KH, KW, stride, pad))
                 call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st)
+                _packed(ent, wst)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:
@@ -259,9 +287,10 @@ class _ConvTranspose2d(Function):
             raise _lib.KernelError("conv_transpose2d: input has %d channels, weight expects %d" % (C, Cw))
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
-        wp, wst = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
+        wp, wst, ent = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
              ptr(wp), wst, conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
+        _packed(ent, wst)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, out_pad, act, slope)
@@ -282,9 +311,10 @@ class _ConvTranspose2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wp, wst = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
+            wp, wst, ent = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
             call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
                  conv_precision, st)
+            _packed(ent, wst)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
             if tgt is None:

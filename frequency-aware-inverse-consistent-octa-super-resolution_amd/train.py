@@ -141,10 +141,34 @@ class ParamArena:
 
 
 def _wait(waiter, on):
-    """``waiter.wait_stream(on)`` unless both roles are the same stream (``TrainStep.stream_layout``): a stream waiting on its own
-    event is a no-op eagerly, but ending a hipGraph capture that recorded one crashes inside the ROCm 7.2 runtime."""
+    """``waiter.wait_stream(on)`` unless both roles are the same stream (``TrainStep.stream_layout``).  A stream waiting on its own
+    event is a no-op eagerly; inside a hipGraph capture it is not harmless on ROCm 7.2 (tools/probe/capture_fork_join.hip,
+    profiles/r03_capture_probe.log), and it is never needed, so it is never issued."""
     if waiter.cuda_stream != on.cuda_stream:
         waiter.wait_stream(on)
+
+
+def _join(waiter, streams):
+    """``waiter`` waits once for each distinct stream of ``streams`` (roles may share streams; never for itself)."""
+    seen = {waiter.cuda_stream}
+    for st in streams:
+        if st is not None and st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            waiter.wait_stream(st)
+
+
+class _Mark:
+    """An event together with the stream it was recorded on, so that a role sharing that stream can skip the wait (see ``_wait``)."""
+    __slots__ = ("event", "sid")
+
+    def __init__(self, stream):
+        self.event, self.sid = stream.record_event(), stream.cuda_stream
+
+
+def _after(waiter, mark):
+    """``waiter`` continues after ``mark`` (no-op for None or a mark of the same stream)."""
+    if mark is not None and waiter.cuda_stream != mark.sid:
+        waiter.wait_event(mark.event)
 
 
 class TrainStep:
@@ -165,6 +189,8 @@ class TrainStep:
     overlap_exchange = True
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
     overlap_min_pixels = 2 * 256 * 256
+    #: the two-chain generator schedule inside a hipGraph capture as well (False: the captured step keeps the single-chain form)
+    capture_two_chains = True
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
@@ -214,7 +240,11 @@ class TrainStep:
             roles = [made.setdefault(ch, torch.cuda.Stream(device=dev, priority=int(prio[int(ch)]) if prio else 0)) for ch in layout]
             self._side, self._side_D, bA, bB, self._idt, self._aba = roles
             self._branch = (bA, bB)
-        self._pack_plan = None            # ops.PackPlan of this step's packed-weight images, built once the first step has run
+        #: ops.PackPlan per (batch shapes, precision): every packed-weight image a step of that shape uses, repacked in ONE launch at
+        #: the step's start.  Per shape, because an image belongs to one (layer, N, H, W): the trailing partial batch of an epoch
+        #: (the reference's DataLoader has no drop_last) gets a plan of its own after its first step instead of invalidating the
+        #: full batches'.  A step without a plan packs inside its convolution calls; ops._wpack orders those across streams by events.
+        self._pack_plans = {}
         if self.distributed:
             if dev.type != "cuda":
                 raise KernelError("TrainStep(distributed=True) needs a GPU: the exchange is RCCL behind the C ABI")
@@ -224,15 +254,32 @@ class TrainStep:
             self.sync_replicas()
 
     def sync_replicas(self, root=0):
-        """Replicas start identical (what DDP's constructor does): rank ``root``'s parameter arenas, AdamW moments and the float
-        buffers (BatchNorm running statistics) of the four networks go to every rank."""
+        """Replicas start identical (what DDP's constructor does): rank ``root``'s parameter arenas, AdamW moments and the
+        buffers of the four networks go to every rank."""
         for a in (self.opt_G, self.opt_D):
             for t in (a.flat, a.exp_avg, a.exp_avg_sq):
                 self.comm.broadcast(t, root)
+        self.sync_buffers(root)
+
+    def sync_buffers(self, root=0):
+        """Rank ``root``'s module buffers (BatchNorm running statistics AND the ``num_batches_tracked`` counters) to every rank.
+        During training each replica's running statistics follow its own shard (they are not read by a training-mode forward);
+        a DDP wrap of the reference would re-broadcast rank 0's before every forward (``broadcast_buffers=True``), so rank 0's
+        checkpoint is the same under both, and the other ranks' buffers differ until this is called: call it before an
+        evaluation or a checkpoint written by a rank other than ``root``."""
+        if self.comm is None:
+            return
         for net in (self.netG_A2B, self.netG_B2A, self.netD_A, self.netD_B):
+            for m in net.modules():                     # counters the HIP BatchNorm keeps on the host reach the tensor first
+                if hasattr(m, "_flush_counter"):
+                    m._flush_counter()
             for b in net.buffers():
-                if b.dtype == torch.float32 and b.numel():
+                if not b.numel():
+                    continue
+                if b.dtype == torch.float32:
                     self.comm.broadcast(b, root)
+                elif b.dtype == torch.int64:            # 8 bytes travel as two floats
+                    self.comm.broadcast(b.reshape(-1).view(torch.float32), root)
 
     # -- pieces of the loop body ---------------------------------------------------------
     def targets(self, B):
@@ -258,7 +305,7 @@ class TrainStep:
         def critic(net, fake, st, key):
             if st is None:
                 return
-            st.wait_stream(main)
+            _wait(st, main)
             fake.record_stream(st)
             with torch.cuda.stream(st):
                 o[key] = net(fake)
@@ -270,12 +317,12 @@ class TrainStep:
                 _, _, o[key] = net(first, second)
                 return None
             st, side = idt
-            st.wait_stream(main)
+            _wait(st, main)
             for t in (first, second, real):
                 t.record_stream(st)
             with torch.cuda.stream(st):
                 _, _, o[key] = net(first, second)
-                ev = st.record_event()
+                ev = _Mark(st)
                 term = ops.l1_loss(real, o[key], self.w["beta2"])           # train.py:230-231
                 ops.wgrad_stream = side
                 try:
@@ -294,8 +341,7 @@ class TrainStep:
             critic(self.netD_B, o["fake_B"], critics[1], "pred_fake_B")
         o["hf_feature_A"] = hf_feature_A.detach()
         hf, lf = ops.freq_split(o["fake_B"], 5, 14)
-        if ev is not None:
-            main.wait_event(ev)
+        _after(main, ev)
         o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)
         hf, lf = ops.freq_split(real_B, 5, 14)
         hf_feature_B, _, o["fake_A"] = G_B2A(hf, lf)
@@ -304,12 +350,11 @@ class TrainStep:
         ev = identity(G_A2B, lf, hf, real_B, "idt_B")                        # netG_A2B's second pass (after fake_B, before recovered_B)
         o["hf_feature_B"] = hf_feature_B.detach()
         hf, lf = ops.freq_split(o["fake_A"], 10, 8)
-        if ev is not None:
-            main.wait_event(ev)
+        _after(main, ev)
         _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)
         if critics:
             for st in critics:
-                main.wait_stream(st)
+                _wait(main, st)
         return o
 
     def _generators_two_chains(self, real_A, real_B):
@@ -331,18 +376,17 @@ class TrainStep:
         o, L = {}, {}
         hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the main stream
         hfB, lfB = ops.freq_split(real_B, 5, 14)
-        ev_in = main.record_event()
+        ev_in = _Mark(main)
         for t in (hfA, lfA, hfB, lfB, real_A, real_B):
             t.record_stream(X)
             t.record_stream(I)
 
         def identity(net, first, second, real, key, after):
-            I.wait_event(ev_in)
-            if after is not None:
-                I.wait_event(after)
+            _after(I, ev_in)
+            _after(I, after)
             with torch.cuda.stream(I):
                 _, _, o[key] = net(first, second)
-                ev = I.record_event()
+                ev = _Mark(I)
                 term = ops.l1_loss(real, o[key], w["beta2"])
                 ops.wgrad_stream = side
                 try:
@@ -358,20 +402,20 @@ class TrainStep:
             fake.record_stream(st)
             with torch.cuda.stream(st):
                 pred = net(fake)
-            return pred, st.record_event()
+            return pred, _Mark(st)
 
         ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                   # B2A pass 1
-        X.wait_event(ev_in)
+        _after(X, ev_in)
         with torch.cuda.stream(X):
             _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                  # A2B pass 1
-            ev_a2b_1 = X.record_event()
+            ev_a2b_1 = _Mark(X)
             o["hf_feature_A"] = hf_feature_A.detach()
             pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, X)
             hf, lf = ops.freq_split(o["fake_B"], 5, 14)
-            X.wait_event(ev_idt_A)
+            _after(X, ev_idt_A)
             o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                # B2A pass 2
-            ev_b2a_2 = X.record_event()
-            X.wait_event(ev_pred_B)
+            ev_b2a_2 = _Mark(X)
+            _after(X, ev_pred_B)                 # (layout "001212": chain A and critic B share a stream -- no wait is issued then)
             pred_B.record_stream(X)
             L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
             L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
@@ -384,15 +428,15 @@ class TrainStep:
                 chain_A.backward()
             finally:
                 ops.wgrad_stream = None
-        main.wait_event(ev_b2a_2)
+        _after(main, ev_b2a_2)
         hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                      # B2A pass 3
         o["hf_feature_B"] = hf_feature_B.detach()
         pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, main)
         ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2
         hf, lf = ops.freq_split(o["fake_A"], 10, 8)
-        main.wait_event(ev_idt_B)
+        _after(main, ev_idt_B)
         _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                    # A2B pass 3
-        main.wait_event(ev_pred_A)
+        _after(main, ev_pred_A)
         pred_A.record_stream(main)
         L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
         L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
@@ -481,7 +525,7 @@ class TrainStep:
                     L[key] = ops.mse_loss(net(real), ones, 0.5) + ops.mse_loss(net(fake.detach()), zeros, 0.5)
                     L[key].backward()
                     continue
-                st.wait_stream(main)
+                _wait(st, main)
                 with torch.cuda.stream(st):                      # autograd runs each node's backward on its forward's stream
                     L[key] = ops.mse_loss(net(real), ones, 0.5) + ops.mse_loss(net(fake.detach()), zeros, 0.5)
                     L[key].backward()
@@ -491,10 +535,7 @@ class TrainStep:
         return fake_A, fake_B            # alive until the branches are joined
 
     def _join_discriminator_phase(self, branches, side):
-        main = torch.cuda.current_stream(self.device)
-        for st in branches:
-            if st is not None:
-                main.wait_stream(st)
+        _join(torch.cuda.current_stream(self.device), branches)
         ops.join_wgrad_stream(side)
 
     def step(self, real_A, real_B, sync=False, keep=False, _static=None):
@@ -508,18 +549,22 @@ class TrainStep:
         ops.conv_precision = ops.PRECISIONS[self.precision]
         ops.reproducible_forward = self.reproducible_forward
         misses = ops.pack_misses
-        packed = self._pack_plan is not None and self._pack_plan.run()     # every packed-weight image of the step in one launch
+        plan_key = (tuple(real_A.shape), tuple(real_B.shape), self.precision)
+        plan = self._pack_plans.get(plan_key)
+        packed = plan is not None and plan.run()        # every packed-weight image of a step of this shape in one launch
         if not packed:
-            self._pack_plan = None
+            self._pack_plans.pop(plan_key, None)
+            ops.clear_touched()                         # ... so that the plan built after this step holds exactly what it used
         # below ~2 x 256^2 pixels per batch the step is bound by the host's enqueue rate, and the extra events / stream switches
         # of the schedule cost more than the concurrency returns (batch 1 at 256^2: 41.8 vs 39.3 ms; batch 2: 48.3 vs 52.8)
         streams = self.overlap_wgrad and self._side is not None and real_A.numel() >= self.overlap_min_pixels
         set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
         self.opt_G.zero_grad()                                              # train.py:220 (before the first backward of a generator term)
-        multi = streams and packed
-        # (ending a hipGraph capture that holds the two-chain pattern crashes inside hipStreamEndCapture on ROCm 7.2: the captured
-        # step keeps the single-chain schedule)
-        two_chains = multi and not torch.cuda.is_current_stream_capturing()
+        # (a step without a plan -- the first of its shape -- packs inside its convolution calls; ops._wpack orders a later reader on
+        # another stream behind that launch by an event, so the schedule, and with it the order of the two gradient exchanges on the
+        # communicator, depends on the batch shape alone, never on rank-local cache state)
+        multi = streams
+        two_chains = multi and (self.capture_two_chains or not torch.cuda.is_current_stream_capturing())
         if two_chains:
             o, L, root = self._generators_two_chains(real_A, real_B)
         else:
@@ -529,9 +574,7 @@ class TrainStep:
             root = L.pop("_root")
         side_G, side_D = (self._side, self._side_D) if streams else (None, None)
         branches = self._branch if streams else (None, None)
-        # a packed image written inside a convolution call is ordered on that call's stream only: the early discriminator phase
-        # needs them all written up front (the plan), i.e. not the first step / a step after the plan was dropped
-        early_D = streams and packed
+        early_D = streams
         held, d_reduced = None, False
         try:
             if early_D:
@@ -549,18 +592,16 @@ class TrainStep:
                 root.backward()
             finally:
                 ops.wgrad_stream = None
-                if multi:                        # the identity terms' / chain A's backward ran on their own streams (BatchNorm affine gradients there)
-                    torch.cuda.current_stream(self.device).wait_stream(self._idt)
-                    torch.cuda.current_stream(self.device).wait_stream(self._aba)
-                    for st in self._branch:      # ... and the frozen discriminator passes' input gradients on the branch streams
-                        torch.cuda.current_stream(self.device).wait_stream(st)
+                if multi:                        # the identity terms' / chain A's backward ran on their own streams (BatchNorm affine gradients
+                    # there), the frozen discriminator passes' input gradients on the branch streams
+                    _join(torch.cuda.current_stream(self.device), (self._idt, self._aba) + tuple(self._branch))
                 ops.join_wgrad_stream(side_G)
             hyper_G = None if _static is None else _static["hyper_G"]
             g_update_aside = self.distributed and streams and self.overlap_exchange
             if g_update_aside:
                 # the generators' gradient exchange and AdamW touch nothing the discriminator phase reads: they run on the side
                 # stream under it and are joined before the discriminators' update
-                side_G.wait_stream(torch.cuda.current_stream(self.device))
+                _wait(side_G, torch.cuda.current_stream(self.device))
                 if d_reduced:                    # one collective at a time on the communicator, in the same order on every rank
                     _wait(side_G, side_D)
                 with torch.cuda.stream(side_G):
@@ -582,8 +623,10 @@ class TrainStep:
             self.opt_D.all_reduce(self.group, self.comm)
         self.opt_D.step(1.0 / self.world, None if _static is None else _static["hyper_D"])
         if ops.pack_misses != misses and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            # some convolution packed its own weights: first step, new batch size or precision -> (re)collect the images this step used
-            self._pack_plan = ops.PackPlan(self.opt_G.params + self.opt_D.params, ops.conv_precision)
+            # some convolution packed its own weights: first step of this shape / precision -> collect the images this step used
+            if len(self._pack_plans) >= 8:
+                self._pack_plans.pop(next(iter(self._pack_plans)))
+            self._pack_plans[plan_key] = ops.PackPlan(self.opt_G.params + self.opt_D.params, ops.conv_precision)
         ops.conv_precision = 0
         ops.reproducible_forward = False
         out = {k: v.detach() for k, v in L.items()}

@@ -155,6 +155,40 @@ def gen_nets(R, H=192, B=2):
     print("nets: done")
 
 
+def gen_eval(R, H=192, B=2):
+    """Inference recipe of utils.py:186,202-205 with the reference's own objects: ``model.eval()`` (BatchNorm2d on running
+    statistics), high_pass / low_pass of the low-resolution image, third output of the generator.  The state is
+    ``make_eval_state`` (non-trivial BatchNorm biases and running statistics), so the eval-mode arithmetic -- and the
+    product's BatchNorm fold -- is exercised.  utils.eval only ever receives netG_A2B (radii 10, 8); B2A (radii 5, 14 of
+    train.py:190) pins the same code path of the other generator."""
+    g = {}
+    lr_img, _ = O.synthetic_batch(B, H, seed=4711)
+    for key, ctor, spec, radii in (("A2B", R.model.NetworkA2B, O.spec_network_a2b(), (10, 8)),
+                                   ("B2A", R.model.NetworkB2A, O.spec_network_b2a(), (5, 14))):
+        model = ctor()
+        state = O.make_eval_state(spec, key, 0)
+        model.load_state_dict(state, strict=True)
+        model.eval()                                                        # utils.py:186
+        outs = []
+        with torch.no_grad():
+            for b in range(B):                                              # utils.py:202-205, one image at a time as there
+                img = lr_img[b:b + 1]
+                hf = R.utils.high_pass(img[0], i=radii[0]).unsqueeze(0).unsqueeze(0)
+                hf = (hf + img) / 2.0
+                lf = R.utils.low_pass(img[0], i=radii[1]).unsqueeze(0).unsqueeze(0)
+                outs.append(model(lf, hf)[2] if key == "A2B" else model(hf, lf)[2])
+        sr = torch.cat(outs)
+        k = key.lower()
+        g["%s_eval_out_stats" % k] = np.array(stats(sr))
+        g["%s_eval_out_c0" % k], g["%s_eval_out_c1" % k] = crops(sr)
+        g["%s_eval_out_rows" % k] = sr[:, 0, H // 2, :].numpy().copy()      # one full row per image
+        for name, v in model.state_dict().items():                          # eval mode leaves the running statistics untouched
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                assert torch.equal(v, state[name]), name
+    np.savez_compressed(os.path.join(OUT, "golden_eval_%d_b%d.npz" % (H, B)), **g)
+    print("eval:", len(g), "arrays")
+
+
 def ref_train_steps(R, H, B, n_steps, seed=0):
     """train.py:73-126 construction + train.py:166-269 loop body, using the
     reference's classes; per-sample split is the only extension (B>1)."""
@@ -228,8 +262,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = ref_shim.load()
-    gen_ops(R)
-    gen_nets(R, 192, 2)
+    if "--eval-only" not in sys.argv:
+        gen_ops(R)
+        gen_nets(R, 192, 2)
+    gen_eval(R, 192, 2)
+    if "--eval-only" in sys.argv:
+        return
     res = []
     for (H, B, n) in ((192, 1, 3), (192, 2, 2), (256, 1, 2)):
         print("step fixtures H=%d B=%d" % (H, B))

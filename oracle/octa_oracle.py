@@ -399,6 +399,23 @@ def make_state(spec, tag, seed=0, dtype=torch.float32):
     return out
 
 
+def make_eval_state(spec, tag, seed=0):
+    """``make_state`` with the state a trained checkpoint has where a fresh one is trivial: BatchNorm biases ~ N(0, 0.1),
+    running means ~ N(0, 0.1), running variances ~ U(0.5, 1.5), each from its own name-keyed generator.  Used by the
+    eval-mode fixtures (oracle/gen_golden.gen_eval: utils.py:186 `model.eval()`), where fresh statistics (0, 1) would make
+    the BatchNorm fold a no-op."""
+    out = make_state(spec, tag, seed)
+    for key, (shape, kind) in spec.items():
+        if kind not in ("bn_b", "bn_rm", "bn_rv"):
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32((tag + "/eval/" + key).encode()) + seed) & 0x7FFFFFFF)
+        if kind == "bn_rv":
+            out[key] = torch.rand(shape, generator=g, dtype=torch.float32) + 0.5
+        else:
+            out[key] = torch.empty(shape, dtype=torch.float32).normal_(0.0, 0.1, generator=g)
+    return out
+
+
 def synthetic_batch(B, H, seed=1234, rank=0):
     """uniform [-1,1) images, the range of Normalize(0.5,0.5) (train.py:133,138)."""
     g = torch.Generator().manual_seed(seed + rank)

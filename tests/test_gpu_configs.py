@@ -140,21 +140,36 @@ def test_config4_rccl_shard_b32_and_run_to_run_spread(fa, O, rccl_world1):
         assert float((other[3] - ref[3]).abs().max()) <= 2.0 * 1.3e-4 * 1.01 + 1e-7, name
 
 
-def test_config5_512_b2_ssim_dwt_graph_vs_oracle(fa, O, rccl_world1):
-    """BASELINE configs[4], one rank's share: 512x512, 2 images, SSIM + 3-level wavelet-HF terms.  (1) eager step vs the CPU
-    oracle: step-0 losses 1e-3, gradient norms 2e-3; (2) the same step as a captured hipGraph with the RCCL exchange inside
-    the capture (world 1): losses follow the eager run over two steps (step 0: 2e-4; step 1: cycle/identity 3e-3)."""
-    B, H = 2, 512
+_cfg5_oracle = {}
+
+
+def _config5_oracle(O):
+    """The fp32 CPU oracle's step 0 at 512^2, batch 2, SSIM + 3-level wavelet-HF terms: computed once for both precisions."""
+    if not _cfg5_oracle:
+        kw = dict(ssim_weight=1.0, whf_weight=0.5, dwt_levels=3)
+        batches = [O.synthetic_batch(2, 512, seed=31 + 5 * s) for s in range(2)]
+        torch.set_num_threads(host_threads())
+        S = O.StepOracle(seed=0, **kw)
+        _cfg5_oracle["L"] = S.train_step(*batches[0])
+        _cfg5_oracle["g"] = S.grad_norms()
+        _cfg5_oracle["batches"] = batches
+        del S
+        gc.collect()
+    return _cfg5_oracle
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config5_512_b2_ssim_dwt_graph_vs_oracle(fa, O, rccl_world1, precision):
+    """BASELINE configs[4], one rank's share: 512x512, 2 images, SSIM + 3-level wavelet-HF terms, at the exact-fp32 precision and
+    at "bf16x3" (the configuration's "bf16" convolutions in their fp32-parity form, DESIGN 4.1b: the first time igemm_bf16x3 /
+    wgrad_x3 run on 512-wide maps and inside a captured graph).  (1) eager step vs the CPU oracle: step-0 losses 1e-3, gradient
+    norms 2e-3; (2) the same step as a captured hipGraph with the RCCL exchange inside the capture (world 1): losses follow the
+    eager run over two steps (step 0: 2e-4; step 1: cycle/identity 3e-3)."""
     kw = dict(ssim_weight=1.0, whf_weight=0.5, dwt_levels=3)
-    batches = [O.synthetic_batch(B, H, seed=31 + 5 * s) for s in range(2)]
-    torch.set_num_threads(host_threads())
-    S = O.StepOracle(seed=0, **kw)
-    Lo = S.train_step(*batches[0])
-    go = S.grad_norms()
-    del S
-    gc.collect()
-    dev = [(x.cuda(), y.cuda()) for x, y in batches]
-    ts = fresh_step(fa, O, distributed=False, **kw)
+    ref = _config5_oracle(O)
+    Lo, go = ref["L"], ref["g"]
+    dev = [(x.cuda(), y.cuda()) for x, y in ref["batches"]]
+    ts = fresh_step(fa, O, distributed=False, precision=precision, **kw)
     Le = []
     for s, (x, y) in enumerate(dev):
         Le.append(ts.step(x, y, sync=True))
@@ -166,7 +181,7 @@ def test_config5_512_b2_ssim_dwt_graph_vs_oracle(fa, O, rccl_world1):
         assert gn[k] == pytest.approx(go[k], rel=2e-3), (k, gn[k], go[k])
     del ts
     torch.cuda.empty_cache()
-    tg = fresh_step(fa, O, distributed=True, **kw)
+    tg = fresh_step(fa, O, distributed=True, precision=precision, **kw)
     gs = fa.GraphedTrainStep(tg, dev[0][0], dev[0][1])
     Lg = [gs.step(x, y, sync=True) for x, y in dev]
     tight = ("loss_G", "loss_cycle_ABA", "loss_cycle_BAB", "loss_idt", "loss_ssim", "loss_whf")

@@ -92,7 +92,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_fwd_bwd(fa, case):
     N, C, H, W, M, k, s, p, reflect, bias, act = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    g = torch.Generator().manual_seed(1000 + CONV_CASES.index(case))      # a function of the case's position: the same data in every process
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(M, C, k, k, generator=g) * 0.05
     b = torch.randn(M, generator=g) if bias else None
@@ -146,7 +146,7 @@ CONVT_CASES = [
 @pytest.mark.parametrize("case", CONVT_CASES)
 def test_conv_transpose2d_fwd_bwd(fa, case):
     N, C, H, W, M, k, s, p, op, bias = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    g = torch.Generator().manual_seed(2000 + CONVT_CASES.index(case))
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(C, M, k, k, generator=g) * 0.05
     b = torch.randn(M, generator=g) if bias else None

@@ -205,6 +205,42 @@ def test_inference_path_eval_mode(fa, O):
     assert ts.opt_G.lr == pytest.approx(0.65e-4) and ts.opt_D.lr == pytest.approx(0.65e-4)
 
 
+def test_super_resolve_vs_reference_eval_fixture(fa, O):
+    """SURVEY 8f-2, generator half, pinned by the REFERENCE: `super_resolve` (frequency split + eval-mode generator with BatchNorm
+    folded into the convolutions) against outputs of the reference's NetworkA2B / NetworkB2A under `model.eval()`
+    (utils.py:186,202-205; tests/golden/golden_eval_192_b2.npz from oracle/gen_golden.gen_eval).  Also the un-folded eval path
+    (BatchNorm eval kernels, taken when gradients are enabled) and that eval mode leaves the running statistics alone."""
+    g = np.load(os.path.join(GOLD, "golden_eval_192_b2.npz"))
+    lr_img, _ = O.synthetic_batch(2, 192, seed=4711)
+    x = lr_img.cuda()
+    for key, cls, spec, radii in (("A2B", fa.NetworkA2B, O.spec_network_a2b(), (10, 8)), ("B2A", fa.NetworkB2A, O.spec_network_b2a(), (5, 14))):
+        state = O.make_eval_state(spec, key, 0)
+        net = cls()
+        net.load_state_dict(state, strict=True)
+        net.cuda()
+        k = key.lower()
+        if key == "A2B":
+            out = fa.super_resolve(net, x)
+        else:
+            net.eval()
+            with torch.no_grad():
+                hf, lf = fa.frequency_split(x, *radii)
+                out = net(hf, lf)[2]
+        assert not net.training
+        o = out.cpu()
+        close(o[0, 0, :8, :8], g["%s_eval_out_c0" % k], rtol=1e-3, atol=2e-4)
+        close(o[-1, -1, -8:, -8:], g["%s_eval_out_c1" % k], rtol=1e-3, atol=2e-4)
+        close(o[:, 0, 96, :], g["%s_eval_out_rows" % k], rtol=1e-3, atol=2e-4)
+        d = o.double()
+        close(np.array([float(d.mean()), float(d.std()), float(d.abs().max()), float(d.abs().mean())]), g["%s_eval_out_stats" % k], rtol=1e-3, atol=1e-5)
+        hf, lf = fa.frequency_split(x, *radii)                  # gradients enabled: BatchNorm eval kernels instead of the fold
+        unfolded = net(lf, hf)[2] if key == "A2B" else net(hf, lf)[2]
+        close(unfolded.detach().cpu(), o.numpy(), rtol=1e-4, atol=2e-5)
+        for name, v in net.state_dict().items():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                assert torch.equal(v.cpu(), state[name]), name
+
+
 @pytest.mark.parametrize("cfg", [2, 0])
 def test_train_step_bf16x3_precision(fa, O, cfg):
     """Opt-in precision "bf16x3" (conv forward / input gradient on hi/lo-split bf16 operands, 3 MFMAs per product): the
@@ -345,9 +381,39 @@ def test_stream_schedule_equals_single_stream(fa, O):
         a, b = O.synthetic_batch(2, 192, seed=99)
         for _ in range(2):
             ts.step(a.cuda(), b.cuda())
-        assert ts._pack_plan is not None          # batched packs are independent of the stream schedule
+        assert len(ts._pack_plans) == 1           # batched packs are independent of the stream schedule
     finally:
         fa.TrainStep.overlap_min_pixels = default
+
+
+def test_trailing_partial_batch_under_stream_schedule(fa, O):
+    """The reference's DataLoader has no drop_last (train.py:142-146): an epoch ends in a smaller batch.  Packed-weight images
+    are per (layer, N, H, W), so that step's images are not in the full batches' pack plan and get packed inside the convolution
+    calls, on whichever stream reaches a layer first; readers on other streams are ordered behind that launch by events
+    (ops._wpack / ops._packed; ADVICE r2: chain A's backward on one stream and an identity pass's backward on another read the
+    same input-gradient image, which used to be an un-ordered torch.empty buffer for one of them).  Steps at batch 4, 4, 3, 4 with
+    the multi-stream schedule against the single-stream one.  lr = 0 keeps the weights (not their packed images: AdamW still bumps
+    the version, so every step repacks) identical on both sides at every step, and ``reproducible_forward`` makes the forward
+    bit-reproducible, so each step's losses agree to 2e-5 and the gradient arenas to 1e-4 relative L2."""
+    part = tuple(t[:3].contiguous() for t in O.synthetic_batch(4, 192, seed=60))
+    batches = [O.synthetic_batch(4, 192, seed=50), O.synthetic_batch(4, 192, seed=51), part, O.synthetic_batch(4, 192, seed=61)]
+    runs = {}
+    for overlap in (False, True):
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], lr=0.0, overlap_wgrad=overlap, reproducible_forward=True)
+        out = []
+        for a, b in batches:
+            L = ts.step(a.cuda(), b.cuda(), sync=True)
+            out.append((L, ts.opt_G.grad.clone(), ts.opt_D.grad.clone()))
+        assert len(ts._pack_plans) == 2                      # one per batch shape; the partial batch did not evict the full batches' plan
+        runs[overlap] = out
+        del ts
+    for i, ((L1, g1, d1), (L0, g0, d0)) in enumerate(zip(runs[True], runs[False])):
+        for k, v in L0.items():
+            assert L1[k] == pytest.approx(v, rel=2e-5, abs=1e-7), (i, k, L1[k], v)
+        for x, y in ((g1, g0), (d1, d0)):
+            assert float((x.double() - y.double()).norm() / y.double().norm()) < 1e-4, i
 
 
 @pytest.mark.gpu

@@ -159,6 +159,29 @@ def test_networks_vs_reference():
     close(st["D_A"]["net.model.3.running_mean"], g["d_a_bn_rm"], rtol=1e-4, atol=1e-6)
 
 
+def test_eval_mode_generators_vs_reference():
+    """SURVEY 8f-2, generator half: the oracle's eval-mode forward (BatchNorm on running statistics) against outputs of the
+    reference's own NetworkA2B / NetworkB2A under `model.eval()` (utils.py:186,202-205; fixture made by oracle/gen_golden.gen_eval
+    with the non-trivial statistics of make_eval_state)."""
+    g = np.load(os.path.join(GOLD, "golden_eval_192_b2.npz"))
+    lr_img, _ = O.synthetic_batch(2, 192, seed=4711)
+    for key, spec, radii in (("A2B", O.spec_network_a2b(), (10, 8)), ("B2A", O.spec_network_b2a(), (5, 14))):
+        st = O.make_eval_state(spec, key, 0)
+        before = {k: v.clone() for k, v in st.items() if k.endswith("running_mean") or k.endswith("running_var")}
+        hf, lf = O.freq_split(lr_img, *radii)
+        with torch.no_grad():
+            net = O.Net(st, train=False)
+            out = O.network_a2b(net, lf, hf)[2] if key == "A2B" else O.network_b2a(net, hf, lf)[2]
+        k = key.lower()
+        close(out[0, 0, :8, :8], g["%s_eval_out_c0" % k], rtol=1e-4, atol=1e-5)
+        close(out[-1, -1, -8:, -8:], g["%s_eval_out_c1" % k], rtol=1e-4, atol=1e-5)
+        close(out[:, 0, 96, :], g["%s_eval_out_rows" % k], rtol=1e-4, atol=1e-5)
+        d = out.double()
+        close(np.array([float(d.mean()), float(d.std()), float(d.abs().max()), float(d.abs().mean())]), g["%s_eval_out_stats" % k], rtol=1e-4, atol=1e-6)
+        for name, v in before.items():
+            assert torch.equal(st[name], v), name
+
+
 def test_train_step_vs_reference():
     """Losses of the restated step vs the reference-object step (192^2, B=1, 2 steps;
     tolerance 1e-3 rel as BASELINE.json's north_star states)."""
