@@ -177,20 +177,31 @@ def hbm_kernels(device, images=512, H=256):
     da, db = torch.empty_like(a), torch.empty_like(b)
     dxh = torch.empty_like(a)
     from faoctasr._lib import call, ptr, stream_ptr
-    cases = (("haar_dwt2d_fwd (DWTForward level, AFB2D)", lambda: ops.haar_afb2d(a), 2 * plane),
+    # vector FMAs per pixel of the separable 11-tap window filters: forward 5 moment maps x (11 row + 11 column taps) = 110;
+    # backward the same 110 plus 5 derivative maps x 22 taps = 220 (the point-wise SSIM algebra, ~40 operations, is not counted)
+    px = images * H * H
+    cases = (("haar_dwt2d_fwd (DWTForward level, AFB2D)", lambda: ops.haar_afb2d(a), 2 * plane, 0),
              ("haar_dwt2d_bwd (AFB2D backward = SFB2D synthesis)",
-              lambda: call("haar_dwt2d_bwd", ptr(ll), ptr(hi), ptr(dxh), images, H, H, stream_ptr()), 2 * plane),
-             ("ssim_fwd (11x11 Gaussian window SSIM, per-image sums)", lambda: ops.ssim(a, b), 2 * plane),
+              lambda: call("haar_dwt2d_bwd", ptr(ll), ptr(hi), ptr(dxh), images, H, H, stream_ptr()), 2 * plane, 0),
+             ("ssim_fwd (11x11 Gaussian window SSIM, per-image sums)", lambda: ops.ssim(a, b), 2 * plane, 110),
              ("ssim_bwd (gradient of the SSIM mean w.r.t. both images)",
-              lambda: call("ssim_bwd", ptr(a), ptr(b), ptr(gsum), images, 1.0, ptr(da), ptr(db), images, 1, H, H, stream_ptr()), 4 * plane))
+              lambda: call("ssim_bwd", ptr(a), ptr(b), ptr(gsum), images, 1.0, ptr(da), ptr(db), images, 1, H, H, stream_ptr()), 4 * plane, 220))
     out = []
     with torch.no_grad():
-        for name, fn, nbytes in cases:
+        for name, fn, nbytes, fma in cases:
             t = timed(fn)
             gbs = nbytes / t / 1e9
-            out.append({"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes, "us": round(t * 1e6, 1),
-                        "sample": "%d planes of %dx%d fp32" % (images, H, H)})
+            row = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": nbytes, "us": round(t * 1e6, 1),
+                   "sample": "%d planes of %dx%d fp32" % (images, H, H)}
+            if fma:
+                # these two are bound by the vector ALU, not by HBM: quote that fraction beside the HBM one.  Peak = the fp32 vector
+                # rate of the spec sheet (157.3 TFLOP/s, which counts v_pk_fma_f32 = 2 FMA per lane and issue slot; a plain
+                # v_fma_f32 stream -- what these filters are, see build.FILE_FLAGS -- tops out at half of it)
+                tf = 2.0 * fma * px / t / 1e12
+                row.update({"valu_tflops": round(tf, 2), "valu_peak_tflops": F32_MFMA_PEAK_TFLOPS, "valu_frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                            "valu_frac_of_unpacked_fma_rate": round(tf / (F32_MFMA_PEAK_TFLOPS / 2), 4), "fma_per_pixel": fma})
+            out.append(row)
     return out
 
 
@@ -316,23 +327,32 @@ def main():
         _lib.launch_timer = None
     if rank == 0 and not args.no_roofline:
         fams = timer.families(nroof)
-        prof = {}
-        for fn in ("r02_mfma_utilisation.json", "r02_traffic.json"):           # rocprofv3 --pmc summaries of this same command
-            fp = os.path.join(ROOT, "profiles", fn)
-            if os.path.exists(fp):
+        # MFMA-busy share and HBM bytes per launch are NOT measured by this run: they are copied from the newest committed summaries of
+        # the builder's own rocprofv3 --pmc passes over this same command (tools/profile_round.sh), and every copy says so
+        import glob
+        prof, src = {}, {}
+        for key, pat in (("mfma", "r[0-9][0-9]_mfma_utilisation.json"), ("traffic", "r[0-9][0-9]_traffic.json")):
+            found = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+            prof[key] = {}
+            if found:
                 try:
-                    prof[fn] = json.load(open(fp)).get("families", {})
+                    prof[key] = json.load(open(found[-1])).get("families", {})
+                    src[key] = "profiles/" + os.path.basename(found[-1])
                 except Exception:
-                    prof[fn] = {}
+                    pass
+        static_note = "static: copied from %s / %s (builder-run rocprofv3 --pmc passes of this command, tools/profile_round.sh), not measured by this run" % (
+            src.get("mfma"), src.get("traffic"))
         for fam, d in fams.items():
-            busy = prof.get("r02_mfma_utilisation.json", {}).get(fam, {}).get("mfma_busy_frac")
+            busy = prof["mfma"].get(fam, {}).get("mfma_busy_frac")
             if busy is not None:
                 d["mfma_busy_frac_rocprof"] = busy
-            d["hbm_bytes_per_launch_rocprof"] = prof.get("r02_traffic.json", {}).get(fam, {}).get("hbm_bytes_per_launch")
+            d["hbm_bytes_per_launch_rocprof"] = prof["traffic"].get(fam, {}).get("hbm_bytes_per_launch")
+            d["rocprof_fields_source"] = static_note
         dom = max(fams, key=lambda k: fams[k]["ms_per_step"])                 # the dominant kernel family BY TIME
         d = fams[dom]
         roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": d["tflops_algorithmic"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": d["frac_algorithmic"], "traffic": d["hbm_bytes_per_launch_rocprof"], "family": dom,
+                "traffic_source": static_note,
                 "definition": "achieved = algorithmic (direct-convolution) FLOP of the family's launches / their HIP-event time; "
                               "frac_executed counts the FLOP the matrix pipe really runs (Winograd: 16/36 of the algorithmic); "
                               "peak = exact-fp32 MFMA at 2.4 GHz -- under this load the chip holds ~2.05-2.1 GHz (DESIGN.md 5)",

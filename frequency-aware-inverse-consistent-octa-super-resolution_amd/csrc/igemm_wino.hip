@@ -7,9 +7,10 @@
 // constant: per-layer error ~1e-6 relative, against the 1e-3 parity bar).
 //
 // Block = 64 output channels x 32 Winograd tiles (2 tile rows x 16 tile columns = 4 x 32 output pixels), 512 threads:
-//   waves 4-7 PRODUCERS: one (tile, channel) pair per thread and 8-channel chunk -- 16 buffer loads (zero padding = offset
-//             past the descriptor's range), B^T d B in registers, 16 scattered LDS stores into V[xi][k][tile]; plus the
-//             LDS-DMA of the chunk's transformed-weight slab U[xi][k][m] (32 KiB contiguous in the packed image);
+//   waves 4-7 PRODUCERS: waves 4-5 transform the input -- alternately, one wave a whole 8-channel chunk: lane = (two adjacent
+//             tiles, channel pair), 48 buffer loads (zero padding = offset past the descriptor's range), B^T d B as packed
+//             float2 arithmetic, 16 ds_write_b128 into V[xi][k][tile][j]; waves 6-7 copy the chunk's transformed-weight slab
+//             U[xi][k][m] (32 KiB contiguous in the packed image) through registers;
 //   waves 0-3 CONSUMERS: wave w owns output channels 16w..16w+15 x all 32 tiles x all 16 Winograd positions xi:
 //             32 accumulator tiles of 16x16 (128 registers).  Because one lane holds all 16 xi of its (channel, tile)
 //             elements, the output transform A^T M A, bias and activation run in registers and results go straight to HBM.
@@ -46,7 +47,16 @@ extern "C" int faoctasr_wino_trace_read(unsigned* host_out, int n) {
 #define WNOW() 0u
 #endif
 #ifndef WINO_ABLATE
-#define WINO_ABLATE 0      // diagnostics, compile time (tools/variants.py): 1 no MFMA, 2 no fragment reads, 4 no patch loads, 8 no V stores, 16 no U DMA, 32 no output stores
+#define WINO_ABLATE 0      // diagnostics, compile time (tools/variants.py): 1 no MFMA, 2 no fragment reads, 4 no patch loads, 8 no V stores, 16 no U DMA, 32 no output stores, 64 patch loads from one 4 KiB window (cache hits: wrong results, same instructions)
+#endif
+#ifndef WINO_UNT
+#define WINO_UNT 0         // experiment: the weight slabs with non-temporal loads
+#endif
+#ifndef WINO_PROD_FIRST
+#define WINO_PROD_FIRST 1  // 1: waves 0-3 produce, 4-7 consume (see `producer` in the kernel); 0: the other way round (round 2)
+#endif
+#ifndef WINO_ROT
+#define WINO_ROT 0         // (experiment, no gain measured: 242-246 vs 229 us on c8) blocks walk the channel chunks in rotated order (see `rot` in the kernel); 0: all in the same order
 #endif
 
 namespace faoctasr {
@@ -77,7 +87,14 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     float* const U_lds = reinterpret_cast<float*>(smem);               // 3 x WN_U_FLOATS (weights are fetched two slabs ahead)
     float* const V_lds = U_lds + 3 * WN_U_FLOATS;                      // 2 x WN_V_FLOATS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
+    // Which waves produce: the SIMD's issue arbiter serves its OLDEST wave first, and an MFMA stream always has its next instruction
+    // queued -- with the consumers in waves 0-3 the co-resident producer wave made progress only while its consumer sat at the
+    // barrier (s_memtime trace, DESIGN.md 4.1a: the transform took ~3000 cycles beside the MFMA loop whatever its instruction
+    // count, ~400 alone; s_setprio did not change that).  Producers first: their few instructions issue when ready and the MFMAs
+    // fill every other slot.
+    const bool producer = WINO_PROD_FIRST ? wave < 4 : wave >= 4;
+    const int T0 = WINO_PROD_FIRST ? 0 : 256, C0 = WINO_PROD_FIRST ? 256 : 0;      // first thread of the producers / consumers (trace stamps)
+    (void)T0; (void)C0;
     const int wn = wave & 3;
     const int tiles_x = (g.OW + 31) >> 5, tiles_y = (g.OH + 3) >> 2;
     const int tiles = tiles_x * tiles_y;
@@ -86,6 +103,11 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     const int mt = blockIdx.y;
     const int nchunks = g.nchunks;
     const long chw = (long)g.IH * g.IW;
+    // The persistent blocks run in step, and with one chunk order they would all stream the SAME 32 KiB slab of transformed weights
+    // at the same moment -- 32 CUs of an XCD asking its L2 for the same lines.  The reduction over channels does not care about
+    // order, so block b starts at chunk rot(b): consecutive blocks of one XCD (ids equal mod 8) get different slabs.
+    const int rot = WINO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
+    auto rot_chunk = [&](int ch) { const int c = ch + rot; return c >= nchunks ? c - nchunks : c; };
     auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {
         n = (int)(tl / tiles);
         const int rt = (int)(tl - (long)n * tiles);
@@ -97,11 +119,11 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         // ================================================ PRODUCER ================================================
         // Slab q = (tile q / nchunks, chunk q % nchunks) of this block's tile sequence; the consumers work on slab q between
         // barrier(q-1) and barrier(q).  Two producer roles, so that each wave's memory counter tracks one kind of traffic:
-        //   waves 4-5 (TRANSFORM): thread = (tile, k) and the two channels k, k+4 of the chunk.  In step q they turn the patch
-        //       of slab q+1 (registers, loaded TWO steps ago) into V[(q+1)&1] and then issue the 32 loads of slab q+3 into the
-        //       same registers; the loads of slab q+2 are in flight meanwhile.  With only plain loads outstanding the compiler
-        //       counts vmcnt exactly (it must wait vmcnt(0) before an LDS store once an LDS-DMA is in flight in the same wave,
-        //       which made the prefetch one step deep and left ~3000 cycles of HBM latency exposed per slab: s_memtime trace).
+        //   waves 4-5 (TRANSFORM), alternating slabs: in step q wave (q+1)&1 turns the patch of slab q+1 (registers, loaded TWO
+        //       steps ago) into V[(q+1)&1] and then issues the loads of slab q+3 into the same registers.  With only plain loads
+        //       outstanding the compiler counts vmcnt exactly (it must wait vmcnt(0) before an LDS store once an LDS-DMA is in
+        //       flight in the same wave, which made the prefetch one step deep and left ~3000 cycles of HBM latency exposed per
+        //       slab: s_memtime trace).
         //   waves 6-7 (WEIGHTS): the transformed-weight slab of slab q+2 into U[(q+2)%3] through registers (see below).
         __builtin_amdgcn_s_setprio(3);                                   // staging ahead of the consumers' MFMA stream in the issue arbiter
         const int stid = tid & 255;
@@ -120,9 +142,15 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             f32x4w wr[16];
             auto load_u = [&](int ch) {
                 if constexpr ((WINO_ABLATE & 16) != 0) return;
-                const float* src = usrc + (long)ch * WN_U_FLOATS;
+                const float* src = usrc + (long)rot_chunk(ch) * WN_U_FLOATS;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) wr[i] = *reinterpret_cast<const f32x4w*>(src + i * 512);
+                for (int i = 0; i < 16; ++i) {
+#if WINO_UNT
+                    wr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4w*>(src + i * 512));
+#else
+                    wr[i] = *reinterpret_cast<const f32x4w*>(src + i * 512);
+#endif
+                }
             };
             auto store_u = [&](int buf) {
                 if constexpr ((WINO_ABLATE & 16) != 0) return;
@@ -150,9 +178,13 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             barrier_u();                                                 // barrier(-1)
             long q = 0;
             for (; q + 3 < q_total; ++q) {
+                WTRACE(tid == T0 + 128, 3072, q, 0, WNOW());
                 next_store_u();                                          // slab q+2
+                WTRACE(tid == T0 + 128, 3072, q, 1, WNOW());
                 next_load_u();                                           // slab q+3
+                WTRACE(tid == T0 + 128, 3072, q, 2, WNOW());
                 barrier_u();
+                WTRACE(tid == T0 + 128, 3072, q, 3, WNOW());
             }
             for (; q < q_total; ++q) {
                 if (q + 2 < q_total) next_store_u();
@@ -162,112 +194,110 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             return;
         }
         // ------------------------------------------------ transform ------------------------------------------------
-        const int tile = stid & 31, kk = stid >> 5;                      // (tile, k 0..3); channels k and k+4
-        const int tr = tile >> 4, tc = tile & 15;
-        f32x2* const vdst0 = reinterpret_cast<f32x2*>(V_lds) + (kk * 32 + (tile ^ (16 * (kk & 1))));     // + xi*128 pairs, + buf*2048 pairs
-        unsigned rowoff[4], coloff[4];
-        __amdgpu_buffer_rsrc_t srd;
-        float dA[2][16], dB[2][16];                                      // patches of even / odd slabs, [channel k / k+4][4x4]
+        // Waves 4 and 5 take the slabs alternately (wave w: slabs w, w+2, ...); one wave transforms a WHOLE slab: lane = (pair of
+        // horizontally adjacent tiles, channel k) with the channels k and k+4 of the chunk packed as float2 operands.  Per slab and
+        // wave: 48 dword loads of the shared 4 x 6 patch (0 address instructions: the per-tile offsets sit in 24 registers, the
+        // chunk's channel advance in the buffer descriptors), 56 v_pk_add_f32 (B^T d per column once for both tiles: 24; (.) B per
+        // tile: 32), 16 ds_write_b128 (V[xi][k][tile A, tile B][j] is 16 contiguous bytes) = 120 vector instructions, against
+        // 2 waves x 145 of round 2's (tile, channel pair) threads (32 loads + 48 address adds + 24 moves + 32 packed adds + 8 stores
+        // each).  On this chip a co-resident wave's vector instructions do not hide behind an f32 MFMA stream, they add to it
+        // (DESIGN.md 4.1a), so the producers' instruction count per slab is what sets the slab period.
+        // Schedule of wave w: in step q with (q + 1) & 1 == w it turns its registers (slab q+1, loaded two steps ago) into
+        // V[(q+1) & 1] and refills them with slab q+3; in the other steps it only meets the barrier.
+        const int tw = __builtin_amdgcn_readfirstlane(stid >> 6);        // 0 / 1; wave-uniform by construction, and the compiler has to know (descriptors in SGPRs)
+        const int tp = lane & 15, kk = lane >> 4;                        // tile pair, channel k (and k + 4)
+        const int tr = tp >> 3, tq = tp & 7;                             // tiles (tr, 2 tq) and (tr, 2 tq + 1) of the block's 2 x 16
+        f32x4w* const vdst0 = reinterpret_cast<f32x4w*>(V_lds) + ((kk * 32 + ((tr * 16 + 2 * tq) ^ (16 * (kk & 1)))) >> 1);   // + xi*64, + buf*1024
+        unsigned voff[4][6];                                             // byte offset of patch element (r, c) of channel k inside the image
+        const float* ximg = x;
+        f32x2 d[4][6];                                                   // [row][column] x (channel k, channel k+4)
         auto set_tile = [&](long tl) {
             int n, ty, tx;
             tile_coords(tl, n, ty, tx);
-            const int iy0 = 4 * ty + 2 * tr + g.oy0, ix0 = 32 * tx + 2 * tc + g.ox0;
+            const int iy0 = 4 * ty + 2 * tr + g.oy0, ix0 = 32 * tx + 4 * tq + g.ox0;
+            unsigned ro[4], co[6];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rowoff[r] = (unsigned)(iy0 + r) < (unsigned)g.IH ? 4u * (unsigned)((iy0 + r) * g.IW) : WN_SENT;
-                coloff[r] = (unsigned)(ix0 + r) < (unsigned)g.IW ? 4u * (unsigned)(ix0 + r) : WN_SENT;
-            }
-            srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (long)n * g.C * chw), 0, (int)((long)g.C * chw * 4), 0x00020000);
+            for (int r = 0; r < 4; ++r) ro[r] = (unsigned)(iy0 + r) < (unsigned)g.IH ? 4u * (unsigned)((iy0 + r) * g.IW) : WN_SENT;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) co[c] = (unsigned)(ix0 + c) < (unsigned)g.IW ? 4u * (unsigned)(ix0 + c) : WN_SENT;
+            const unsigned koff = 4u * (unsigned)(kk * (int)chw);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    voff[r][c] = ((ro[r] | co[c]) & WN_SENT) ? WN_SENT : ro[r] + co[c] + koff;
+                    if constexpr ((WINO_ABLATE & 64) != 0) voff[r][c] = (voff[r][c] & 0xffcu) | ((unsigned)kk << 12);
+                }
+            ximg = x + (long)n * g.C * chw;
         };
-        auto load_d = [&](float (&d)[2][16], int ch) {
+        auto load_d = [&](int ch) {
             if constexpr ((WINO_ABLATE & 4) != 0) return;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned coff = 4u * (unsigned)((ch * WN_KC + kk + 4 * j) * (int)chw);   // past the range for c >= C: reads 0
+                // the descriptor starts at channel ch*8 + 4j and ends with the image: a lane whose channel k + 4j + 8 ch >= C reads 0
+                const int c0 = (WINO_ABLATE & 64) ? 4 * j : rot_chunk(ch) * WN_KC + 4 * j;
+                const int left = g.C - c0 > 0 ? g.C - c0 : 0;
+                const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(((WINO_ABLATE & 64) ? x : ximg) + (long)c0 * chw), 0, (int)((long)left * chw * 4), 0x00020000);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        d[j][r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, coff + rowoff[r] + coloff[c], 0, 0));
+                    for (int c = 0; c < 6; ++c) d[r][c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, voff[r][c], 0, 0));
             }
         };
-        auto store_v = [&](const float (&d)[2][16], int buf) {
+        auto store_v = [&](int buf) {
             if constexpr ((WINO_ABLATE & 8) != 0) return;
-            f32x2* vd = vdst0 + buf * (WN_V_FLOATS / 2);
-            float t[2][4][4];
+            f32x4w* vd = vdst0 + buf * (WN_V_FLOATS / 4);
+            f32x2 t[4][6];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int c = 0; c < 6; ++c) {                                // B^T d, once per patch column (shared by the two tiles)
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {                            // B^T d
-                    t[j][0][c] = d[j][0 + c] - d[j][8 + c];
-                    t[j][1][c] = d[j][4 + c] + d[j][8 + c];
-                    t[j][2][c] = d[j][8 + c] - d[j][4 + c];
-                    t[j][3][c] = d[j][4 + c] - d[j][12 + c];
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                                // (.) B; one 8-byte store per Winograd position
-                vd[(r * 4 + 0) * 128] = f32x2{t[0][r][0] - t[0][r][2], t[1][r][0] - t[1][r][2]};
-                vd[(r * 4 + 1) * 128] = f32x2{t[0][r][1] + t[0][r][2], t[1][r][1] + t[1][r][2]};
-                vd[(r * 4 + 2) * 128] = f32x2{t[0][r][2] - t[0][r][1], t[1][r][2] - t[1][r][1]};
-                vd[(r * 4 + 3) * 128] = f32x2{t[0][r][1] - t[0][r][3], t[1][r][1] - t[1][r][3]};
+            for (int r = 0; r < 4; ++r) {                                // (.) B per tile; one 16-byte store per Winograd position
+                const f32x2 a0 = t[r][0] - t[r][2], b0 = t[r][2] - t[r][4];
+                const f32x2 a1 = t[r][1] + t[r][2], b1 = t[r][3] + t[r][4];
+                const f32x2 a2 = t[r][2] - t[r][1], b2 = t[r][4] - t[r][3];
+                const f32x2 a3 = t[r][1] - t[r][3], b3 = t[r][3] - t[r][5];
+                vd[(r * 4 + 0) * 64] = f32x4w{a0[0], a0[1], b0[0], b0[1]};
+                vd[(r * 4 + 1) * 64] = f32x4w{a1[0], a1[1], b1[0], b1[1]};
+                vd[(r * 4 + 2) * 64] = f32x4w{a2[0], a2[1], b2[0], b2[1]};
+                vd[(r * 4 + 3) * 64] = f32x4w{a3[0], a3[1], b3[0], b3[1]};
             }
         };
-        long tl_load = blockIdx.x;                                      // (tile, chunk) of the patch-load cursor
-        int ch_load = 0;
-        auto next_load = [&](float (&d)[2][16]) {
-            if (++ch_load == nchunks) {
-                ch_load = 0;
+        long tl_load = blockIdx.x;                                       // (tile, chunk) of this wave's load cursor: slabs tw, tw + 2, ...
+        int ch_load = tw;
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        auto next_load = [&]() {                                         // two slabs on (nchunks >= 2)
+            ch_load += 2;
+            if (ch_load >= nchunks) {
+                ch_load -= nchunks;
                 tl_load += gridDim.x;
                 set_tile(tl_load);
             }
-            load_d(d, ch_load);
+            load_d(ch_load);
         };
-        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-        // prologue: slab 0 -> V[0]; slabs 1 and 2 in flight (dB, dA)
+        // prologue: wave 0 puts slab 0 into V[0] and fetches slab 2; wave 1 fetches slab 1 (stored in step 0)
         set_tile(tl_load);
-        load_d(dA, 0);
-        if (q_total > 1) next_load(dB);
-        store_v(dA, 0);
-        if (q_total > 2) next_load(dA);
-        barrier();                                                       // barrier(-1)
-        // Steady state without conditions around the loads: the compiler's vmcnt model only counts what is issued on EVERY path, so a
-        // guarded next_load made every store_v wait for the newest batch as well (vmcnt 31..0 instead of 63..32) -- found by
-        // reading the ISA after the s_memtime trace showed store_v still waiting ~2600 cycles.
-        long q = 0;
-        for (; q + 4 < q_total; q += 2) {
-            WTRACE(tid == 256, 1024, q, 0, WNOW());
-            store_v(dB, 1);                                              // slab q+1
-            WTRACE(tid == 256, 1024, q, 1, WNOW());
-            next_load(dB);                                               // slab q+3
-            WTRACE(tid == 256, 1024, q, 2, WNOW());
-            barrier();
-            WTRACE(tid == 256, 1024, q, 3, WNOW());
-            WTRACE(tid == 256, 1024, q + 1, 0, WNOW());
-            store_v(dA, 0);                                              // slab q+2
-            WTRACE(tid == 256, 1024, q + 1, 1, WNOW());
-            next_load(dA);                                               // slab q+4
-            WTRACE(tid == 256, 1024, q + 1, 2, WNOW());
-            barrier();
-            WTRACE(tid == 256, 1024, q + 1, 3, WNOW());
+        if (tw < q_total) load_d(ch_load);
+        if (tw == 0) {
+            store_v(0);
+            if (2 < q_total) next_load();
         }
-        for (; q < q_total; q += 2) {                                    // the last steps, guarded
-            // step q (even): slab q+1 sits in dB
-            WTRACE(tid == 256, 1024, q, 0, WNOW());
-            if (q + 1 < q_total) store_v(dB, 1);
-            WTRACE(tid == 256, 1024, q, 1, WNOW());
-            if (q + 3 < q_total) next_load(dB);
-            WTRACE(tid == 256, 1024, q, 2, WNOW());
+        barrier();                                                       // barrier(-1)
+        for (long q = 0; q < q_total; ++q) {
+            WTRACE(tid == T0, 1024, q, 0, WNOW());
+            if (((int)(q + 1) & 1) == tw && q + 1 < q_total) {           // wave-uniform
+                store_v(tw);                                             // slab q+1
+                WTRACE(tid == T0, 1024, q, 1, WNOW());
+                if (q + 3 < q_total) next_load();                        // slab q+3
+            }
+            WTRACE(tid == T0, 1024, q, 2, WNOW());
             barrier();
-            WTRACE(tid == 256, 1024, q, 3, WNOW());
-            if (q + 1 >= q_total) break;
-            // step q+1 (odd): slab q+2 sits in dA
-            WTRACE(tid == 256, 1024, q + 1, 0, WNOW());
-            if (q + 2 < q_total) store_v(dA, 0);
-            WTRACE(tid == 256, 1024, q + 1, 1, WNOW());
-            if (q + 4 < q_total) next_load(dA);
-            WTRACE(tid == 256, 1024, q + 1, 2, WNOW());
-            barrier();
-            WTRACE(tid == 256, 1024, q + 1, 3, WNOW());
+            WTRACE(tid == T0, 1024, q, 3, WNOW());
         }
         return;
     }
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             const unsigned ua = ua0 + (unsigned)ub * (WN_U_FLOATS * 4u), vb = vb0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u),
                            vc = vc0 + (unsigned)(slab & 1) * (WN_V_FLOATS * 4u);
             ub = ub == 2 ? 0 : ub + 1;
-            WTRACE(tid == 0, 2048, slab, 0, WNOW());
+            WTRACE(tid == C0, 2048, slab, 0, WNOW());
             if (pmask) st_pair(ch);
             // fragment reads run two xi steps (8 MFMAs = 256 cycles) ahead of their use
             f32x2 a[3], b0[3], b1[3];
@@ -397,9 +427,9 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            WTRACE(tid == 0, 2048, slab, 1, WNOW());
+            WTRACE(tid == C0, 2048, slab, 1, WNOW());
             asm volatile("s_barrier" ::: "memory");                      // all LDS reads of this slab retired (lgkmcnt(0) above)
-            WTRACE(tid == 0, 2048, slab, 2, WNOW());
+            WTRACE(tid == C0, 2048, slab, 2, WNOW());
         }
         // ---- output transform of this tile into the pending registers (the producers are already staging the next tile)
         {

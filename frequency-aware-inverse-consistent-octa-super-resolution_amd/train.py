@@ -190,7 +190,7 @@ class TrainStep:
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
     overlap_min_pixels = 2 * 256 * 256
     #: the two-chain generator schedule inside a hipGraph capture as well (False: the captured step keeps the single-chain form)
-    capture_two_chains = True
+    capture_two_chains = False
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,

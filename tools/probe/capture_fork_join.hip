@@ -55,7 +55,33 @@ static int run_pattern(int id, hipStreamCaptureMode mode) {
             c.k(X);
             hipEvent_t e = c.rec(X);
             c.k(X);
+            printf("    before the self-wait\n"); fflush(stdout);
             c.wait(X, e);
+            printf("    after the self-wait\n"); fflush(stdout);
+            c.k(X);
+            printf("    after the next kernel\n"); fflush(stdout);
+            c.join(M, X);
+            printf("    joined\n"); fflush(stdout);
+            break;
+        }
+        case 8: {                                            // the same with nothing between record and wait
+            c.join(X, M);
+            c.k(X);
+            hipEvent_t e = c.rec(X);
+            printf("    before the self-wait\n"); fflush(stdout);
+            c.wait(X, e);
+            printf("    after the self-wait\n"); fflush(stdout);
+            c.k(X);
+            c.join(M, X);
+            printf("    joined\n"); fflush(stdout);
+            break;
+        }
+        case 9: {                                            // forked stream waits on an event of the ORIGIN recorded before the fork (redundant edge across streams)
+            hipEvent_t e0 = c.rec(M);
+            c.k(M);
+            c.join(X, M);
+            c.k(X);
+            c.wait(X, e0);
             c.k(X);
             c.join(M, X);
             break;
@@ -131,9 +157,10 @@ static int run_pattern(int id, hipStreamCaptureMode mode) {
 
 int main() {
     const char* names[] = {"fork/join", "self-wait right after record", "self-wait after a kernel", "self-wait on a forked stream",
-                           "two-chain shape (no self-waits)", "unjoined fork", "one event waited on repeatedly", "double join"};
-    for (int mode = 0; mode < 2; ++mode)
-        for (int id = 0; id < 8; ++id) {
+                           "two-chain shape (no self-waits)", "unjoined fork", "one event waited on repeatedly", "double join",
+                           "self-wait on a forked stream, right after record", "forked stream waits on an older event of the origin"};
+    for (int mode = 1; mode < 2; ++mode)        // (Global and ThreadLocal behaved identically: profiles/r03_capture_probe.log)
+        for (int id = 0; id < 10; ++id) {
             printf("[%s] pattern %d: %s\n", mode ? "ThreadLocal" : "Global", id, names[id]);
             fflush(stdout);
             pid_t pid = fork();

@@ -64,9 +64,17 @@ def main():
                "two_chains=0,selfwait=1,layout=001212", "two_chains=1,selfwait=1,layout=001212", "two_chains=1,selfwait=1,layout=012345"]
     if len(sys.argv) > 1:
         configs = sys.argv[1:]
-    env = dict(os.environ, PYTHONFAULTHANDLER="1", AMD_LOG_LEVEL=os.environ.get("AMD_LOG_LEVEL", "1"))
+    env0 = dict(os.environ, PYTHONFAULTHANDLER="1", AMD_LOG_LEVEL=os.environ.get("AMD_LOG_LEVEL", "1"))
+    shim = os.path.join(ROOT, "tools", "probe", "bin", "libhipcaptrace.so")
+    outdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
     for spec in configs:
         print("=== %s" % spec, flush=True)
+        env = dict(env0)
+        trace = None
+        if os.environ.get("CAPTRACE") and os.path.exists(shim):        # record the capture's event / wait / launch sequence (hip_capture_trace.cpp)
+            trace = os.path.join(outdir, "captrace_%s.txt" % spec.replace(",", "_").replace("=", ""))
+            env.update(LD_PRELOAD=shim, HIPCAPTRACE_OUT=trace)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", spec], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                timeout=420)
@@ -76,6 +84,10 @@ def main():
         lines = out.strip().splitlines()
         print("\n".join("    " + l for l in lines[-40:]))
         print("    ==> exit %s%s" % (rc, " (signal %d)" % -rc if isinstance(rc, int) and rc < 0 else ""), flush=True)
+        if trace and os.path.exists(trace):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "capture_trace_report.py"), trace], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT)
+            print("\n".join("    | " + l for l in r.stdout.decode(errors="replace").splitlines()), flush=True)
 
 
 if __name__ == "__main__":

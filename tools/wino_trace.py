@@ -16,7 +16,7 @@ t = np.frombuffer(raw, dtype=np.uint32).astype("int64")
 p = t[1024:1152].reshape(32, 4); c = t[2048:2176].reshape(32, 4); u = t[3072:3200].reshape(32, 4)
 d = lambda a, b: int((a - b) & 0xffffffff)
 print("slab | transform wave: store_v  loads  barrier | weights wave: store  loads  barrier | consumer: mfma-loop  barrier  (to next slab start)")
-for i in range(24):
+for i in range(16):
     nxt = d(c[i + 1][0], c[i][2]) if i + 1 < 32 else 0
     print("%4d | %6d %6d %6d | %6d %6d %6d | %6d %6d %6d" % (16 + i, d(p[i][1], p[i][0]), d(p[i][2], p[i][1]), d(p[i][3], p[i][2]),
           d(u[i][1], u[i][0]), d(u[i][2], u[i][1]), d(u[i][3], u[i][2]), d(c[i][1], c[i][0]), d(c[i][2], c[i][1]), nxt))
