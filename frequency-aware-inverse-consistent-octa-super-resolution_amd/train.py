@@ -190,7 +190,7 @@ class TrainStep:
     #: the multi-stream schedule is used from this many pixels per batch on (``overlap_wgrad`` permitting); tests set 0
     overlap_min_pixels = 2 * 256 * 256
     #: the two-chain generator schedule inside a hipGraph capture as well (False: the captured step keeps the single-chain form)
-    capture_two_chains = False
+    capture_two_chains = True
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
@@ -360,30 +360,41 @@ class TrainStep:
     def _generators_two_chains(self, real_A, real_B):
         """The generator phase (train.py:173-236) as two chains on two streams:
 
-            chain A (stream ``_aba``):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
-            chain B (main stream)    :  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
-            identity passes (``_idt``) and the frozen discriminator passes (branch streams) as in ``forward_generators``
+            chain A (caller's stream):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
+            chain B (stream ``_aba``):  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
+            identity passes (``_idt``) with their loss terms and backward; the frozen discriminator of chain A on a branch stream,
+            the one of chain B on chain B's own stream
 
         Chain A's loss terms depend on nothing chain B computes, so its backward -- a third of the generators' backward work -- runs
         under chain B's forward.  Each network's three passes keep the reference's order (A2B: real_A, real_B, fake_A; B2A: real_A,
         fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence.  Returns (o, L, root):
-        ``root`` is what is left to back-propagate (chain B's terms)."""
+        ``root`` is what is left to back-propagate (chain B's terms).
+
+        Which chain sits on which stream is dictated by hipGraph capture (profiles/r03_capture_crash_gdb_*.log): when a
+        forked stream waits on an event of another forked stream, the HIP runtime lists the waiter as a "parallel capture stream" of
+        the other, and ``hip::Stream::EndCapture`` walks those lists recursively without a visited set -- two forked streams that
+        wait on each other (round 2's layout: chain A on a forked stream needed an identity-pass event and the identity stream
+        needed a chain-A event) recurse until the stack overflows.  Waits to and from the capture's ORIGIN stream are never listed.
+        So the chain both other roles depend on runs on the caller's stream (the origin under capture), and among the forked streams
+        the waits form a DAG: ``_idt`` waits only on the caller, ``_aba`` on the caller and on ``_idt``, the weight-gradient stream
+        on everybody, nobody but the caller on it."""
         G_A2B, G_B2A, w = self.netG_A2B, self.netG_B2A, self.w
         ones, _ = self.targets(real_A.shape[0])
         main = torch.cuda.current_stream(self.device)
-        X, I, side = self._aba, self._idt, self._side
-        cA, cB = self._branch
+        Q, I, side = self._aba, self._idt, self._side
+        cB = self._branch[1]
+        if cB.cuda_stream == Q.cuda_stream:      # chain A's frozen discriminator must not share chain B's stream (it would wait on the caller
+            cB = self._branch[0]                 # and be waited on by it from inside chain B's work); any other branch stream will do
         o, L = {}, {}
-        hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the main stream
+        hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the caller's stream
         hfB, lfB = ops.freq_split(real_B, 5, 14)
         ev_in = _Mark(main)
         for t in (hfA, lfA, hfB, lfB, real_A, real_B):
-            t.record_stream(X)
+            t.record_stream(Q)
             t.record_stream(I)
 
         def identity(net, first, second, real, key, after):
-            _after(I, ev_in)
-            _after(I, after)
+            _after(I, after)                                # always an event of the caller's stream
             with torch.cuda.stream(I):
                 _, _, o[key] = net(first, second)
                 ev = _Mark(I)
@@ -397,67 +408,72 @@ class TrainStep:
             term.record_stream(main)
             return ev, term.detach()
 
-        def critic(net, fake, st, src):
-            _wait(st, src)
-            fake.record_stream(st)
-            with torch.cuda.stream(st):
-                pred = net(fake)
-            return pred, _Mark(st)
-
-        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                   # B2A pass 1
-        _after(X, ev_in)
-        with torch.cuda.stream(X):
-            _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                  # A2B pass 1
-            ev_a2b_1 = _Mark(X)
-            o["hf_feature_A"] = hf_feature_A.detach()
-            pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, X)
-            hf, lf = ops.freq_split(o["fake_B"], 5, 14)
-            _after(X, ev_idt_A)
-            o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                # B2A pass 2
-            ev_b2a_2 = _Mark(X)
-            _after(X, ev_pred_B)                 # (layout "001212": chain A and critic B share a stream -- no wait is issued then)
-            pred_B.record_stream(X)
-            L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
-            L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
-            chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
-            extra_A = self._extension_terms(o["recovered_A"], real_A)
-            for k, v in extra_A.items():
-                chain_A = chain_A + v
-            ops.wgrad_stream = side
-            try:
-                chain_A.backward()
-            finally:
-                ops.wgrad_stream = None
-        _after(main, ev_b2a_2)
-        hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                      # B2A pass 3
-        o["hf_feature_B"] = hf_feature_B.detach()
-        pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, main)
-        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2
-        hf, lf = ops.freq_split(o["fake_A"], 10, 8)
-        _after(main, ev_idt_B)
-        _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                    # A2B pass 3
-        _after(main, ev_pred_A)
-        pred_A.record_stream(main)
-        L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
-        L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
-            ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
-        root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", ev_in)                 # B2A pass 1
+        # ---- chain A, forward (caller's stream)
+        _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                      # A2B pass 1
+        ev_a2b_1 = _Mark(main)
+        o["hf_feature_A"] = hf_feature_A.detach()
+        _wait(cB, main)
+        o["fake_B"].record_stream(cB)
+        with torch.cuda.stream(cB):
+            pred_B = self.netD_B(o["fake_B"])
+            ev_pred_B = _Mark(cB)
+        hf, lf = ops.freq_split(o["fake_B"], 5, 14)
+        _after(main, ev_idt_A)
+        o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                    # B2A pass 2
+        ev_b2a_2 = _Mark(main)
+        # ---- chain B, forward (its own stream), enqueued before chain A's backward so that the two overlap
+        _after(Q, ev_b2a_2)                                                                 # (implies ev_in)
+        with torch.cuda.stream(Q):
+            hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                  # B2A pass 3
+            o["hf_feature_B"] = hf_feature_B.detach()
+            ev_fake_A = _Mark(Q)
+            pred_A = self.netD_A(o["fake_A"])                                               # chain B's frozen discriminator, on chain B's stream
+            hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2 (after pass 1 on the caller's stream)
+        _after(Q, ev_idt_B)
+        with torch.cuda.stream(Q):
+            _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                # A2B pass 3
+            L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
+            L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
+                ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
+            root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+            extra_B = self._extension_terms(o["recovered_B"], real_B)       # opt-in SSIM / wavelet-HF terms: one half per chain
+            for k, v in extra_B.items():
+                root = root + v
+        # ---- chain A, losses and backward (caller's stream)
+        _after(main, ev_pred_B)
+        pred_B.record_stream(main)
+        L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
+        L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
+        chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
+        extra_A = self._extension_terms(o["recovered_A"], real_A)
+        for k, v in extra_A.items():
+            chain_A = chain_A + v
+        ops.wgrad_stream = side
+        try:
+            chain_A.backward()
+        finally:
+            ops.wgrad_stream = None
+        # ---- the caller's stream picks up what chain B has produced so far (fake_A feeds the replay buffer and the discriminator phase;
+        # the loss scalars are read after the step's final joins)
+        _after(main, ev_fake_A)
         done = None
-        for k, v in self._extension_terms(o["recovered_B"], real_B).items():        # opt-in SSIM / wavelet-HF terms: one half per chain
-            root = root + v
-            extra_A[k].record_stream(main)
-            L[k] = v + extra_A[k].detach()
+        for k, v in extra_B.items():
+            v.record_stream(main)
             done = extra_A[k].detach() if done is None else done + extra_A[k].detach()
         for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
-            L[k].record_stream(main)
             L[k] = L[k].detach()
-        for k in ("fake_B", "hf_feature_A", "hf_feature_recovered_A", "recovered_A"):
+        for k in ("fake_A", "hf_feature_B", "hf_feature_recovered_B", "recovered_B"):
             o[k].record_stream(main)
+        for k in ("loss_GAN_B2A", "loss_cycle_BAB"):
+            L[k].record_stream(main)
+        root.record_stream(main)
         L["loss_idt"] = idt_A + idt_B
         o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
-        L["loss_G"] = root.detach() + L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"]
-        if done is not None:
-            L["loss_G"] = L["loss_G"] + done
+        # totals that mix the two chains are formed by ``step`` after it has joined chain B's stream
+        self._chain_B_terms = (root, L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"], done,
+                               {k: (extra_A[k].detach(), v) for k, v in extra_B.items()})
         return o, L, root
 
     def _extension_terms(self, rec, real):
@@ -596,6 +612,12 @@ class TrainStep:
                     # there), the frozen discriminator passes' input gradients on the branch streams
                     _join(torch.cuda.current_stream(self.device), (self._idt, self._aba) + tuple(self._branch))
                 ops.join_wgrad_stream(side_G)
+            if two_chains:                       # chain B's terms were computed on its stream: the total is formed after the join
+                root_B, rest, done, halves = self._chain_B_terms
+                L["loss_G"] = root_B.detach() + rest if done is None else root_B.detach() + rest + done
+                for k, (ha, hb) in halves.items():
+                    L[k] = ha + hb.detach()
+                self._chain_B_terms = None
             hyper_G = None if _static is None else _static["hyper_G"]
             g_update_aside = self.distributed and streams and self.overlap_exchange
             if g_update_aside:

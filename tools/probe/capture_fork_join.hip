@@ -8,6 +8,7 @@
 #include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("    %s -> %s\n", #x, hipGetErrorString(e_)); fflush(stdout); _exit(10); } } while (0)
@@ -133,6 +134,36 @@ static int run_pattern(int id, hipStreamCaptureMode mode) {
             c.k(M);
             break;
         }
+        case 10: {                                           // an event recorded in the capture is DESTROYED before the capture ends,
+            c.join(X, M);                                    // and its memory is handed to something else
+            for (int r = 0; r < 64; ++r) {
+                c.k(X);
+                hipEvent_t e;
+                CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                CK(hipEventRecord(e, c.s[X]));
+                CK(hipStreamWaitEvent(c.s[I], e, 0));
+                c.k(I);
+                CK(hipEventDestroy(e));
+                void* junk[8];
+                for (auto& j : junk) { j = malloc(64 + 16 * (r & 7)); memset(j, 0xff, 64); }
+                for (auto& j : junk) if ((reinterpret_cast<size_t>(j) >> 4) & 1) free(j);       // (half of them stay: the freed event's block gets reused)
+            }
+            c.join(M, X); c.join(M, I);
+            break;
+        }
+        case 11: {                                           // two forked streams wait on each other's events (what the two-chain schedule does)
+            hipEvent_t e0 = c.rec(M);
+            c.wait(X, e0); c.wait(I, e0);
+            c.k(X);
+            hipEvent_t e1 = c.rec(X);
+            c.wait(I, e1);                                   // I after X
+            c.k(I);
+            hipEvent_t e2 = c.rec(I);
+            c.wait(X, e2);                                   // X after I
+            c.k(X);
+            c.join(M, X); c.join(M, I);
+            break;
+        }
         default: break;
     }
     hipGraph_t g = nullptr;
@@ -158,9 +189,10 @@ static int run_pattern(int id, hipStreamCaptureMode mode) {
 int main() {
     const char* names[] = {"fork/join", "self-wait right after record", "self-wait after a kernel", "self-wait on a forked stream",
                            "two-chain shape (no self-waits)", "unjoined fork", "one event waited on repeatedly", "double join",
-                           "self-wait on a forked stream, right after record", "forked stream waits on an older event of the origin"};
+                           "self-wait on a forked stream, right after record", "forked stream waits on an older event of the origin",
+                           "events recorded in the capture and destroyed before it ends", "two forked streams wait on each other"};
     for (int mode = 1; mode < 2; ++mode)        // (Global and ThreadLocal behaved identically: profiles/r03_capture_probe.log)
-        for (int id = 0; id < 10; ++id) {
+        for (int id = 0; id < 12; ++id) {
             printf("[%s] pattern %d: %s\n", mode ? "ThreadLocal" : "Global", id, names[id]);
             fflush(stdout);
             pid_t pid = fork();

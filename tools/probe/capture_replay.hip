@@ -41,6 +41,7 @@ static std::vector<Op> load(const char* path) {
         if (k == "B" || k == "E") ops.push_back({k[0], w[1], "", 0});
         else if (k == "K" || k == "M") ops.push_back({'K', w[1], "", th});
         else if (k == "R" || k == "W") ops.push_back({k[0], w[1], w[2], th});      // R event stream / W stream event
+        else if (k == "C" || k == "D") ops.push_back({k[0], w[1], "", th});        // event created / destroyed (same handle = the allocator reused the block)
     }
     return ops;
 }
@@ -77,6 +78,17 @@ static int replay(const std::vector<Op>& ops, bool verbose) {
         switch (o.k) {
             case 'B': origin = S(o.a); e = hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal); break;
             case 'K': hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, S(o.a), buf); e = hipGetLastError(); break;
+            case 'C': {
+                hipEvent_t n;
+                e = hipEventCreateWithFlags(&n, hipEventDisableTiming);
+                ev[o.a] = n;                                  // (an event created before the trace began keeps its lazily made stand-in)
+                break;
+            }
+            case 'D': {
+                auto it = ev.find(o.a);
+                if (it != ev.end()) { e = hipEventDestroy(it->second); ev.erase(it); }
+                break;
+            }
             case 'R': e = hipEventRecord(E(o.a), S(o.b)); break;
             case 'W': e = hipStreamWaitEvent(S(o.a), E(o.b), 0); break;
             case 'E': {
@@ -133,6 +145,7 @@ static void dump(const std::vector<Op>& ops, const char* path) {
     for (const Op& o : ops) {
         if (o.k == 'R') fprintf(f, "R %s %s tid %d\n", nm(en, o.a, "e").c_str(), nm(sn, o.b, "s").c_str(), o.th);
         else if (o.k == 'W') fprintf(f, "W %s %s tid %d\n", nm(sn, o.a, "s").c_str(), nm(en, o.b, "e").c_str(), o.th);
+        else if (o.k == 'C' || o.k == 'D') fprintf(f, "%c %s tid %d\n", o.k, nm(en, o.a, "e").c_str(), o.th);
         else fprintf(f, "%c %s tid %d\n", o.k, nm(sn, o.a, "s").c_str(), o.th);
     }
     fclose(f);

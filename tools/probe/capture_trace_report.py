@@ -13,6 +13,7 @@ def main(path):
     last_work_seq, joined_at = defaultdict(int), {}
     seq = 0
     tids = Counter()
+    dead_recorded = []
 
     def nm(s):
         if s not in names:
@@ -53,6 +54,9 @@ def main(path):
                 capturing.add(s)
             if s == origin:
                 joined_at[src] = seq
+        elif k == "D":
+            if p[1] in rec_on:
+                dead_recorded.append(p[1])
         elif k == "E":
             for s in capturing:
                 if s != origin and last_work_seq[s] > joined_at.get(s, 0):
@@ -62,6 +66,7 @@ def main(path):
     print("work items per stream:", dict(work))
     print("issuing threads per stream:", dict(tids))
     print("waits (waiter <- recorded on):", dict(waits))
+    print("events destroyed during the capture after having been recorded in it: %d" % len(dead_recorded))
     print("%d anomalies" % len(anomalies))
     for a in anomalies[:60]:
         print("  ", a)

@@ -46,6 +46,8 @@ def child(spec):
     eager = [ts.step(a, b, sync=True) for a, b in batches]
     del ts
     tg = fresh()
+    print("stream handles: caller-side roles", {k: hex(getattr(tg, k).cuda_stream) for k in ("_side", "_side_D", "_idt", "_aba")},
+          "branches", [hex(b.cuda_stream) for b in tg._branch], flush=True)
     print("capturing ...", flush=True)
     gs = faoctasr.GraphedTrainStep(tg, *batches[0])
     print("captured", flush=True)
@@ -75,6 +77,8 @@ def main():
         if os.environ.get("CAPTRACE") and os.path.exists(shim):        # record the capture's event / wait / launch sequence (hip_capture_trace.cpp)
             trace = os.path.join(outdir, "captrace_%s.txt" % spec.replace(",", "_").replace("=", ""))
             env.update(LD_PRELOAD=shim, HIPCAPTRACE_OUT=trace)
+            if "defer=1" in spec:
+                env["HIPCAPTRACE_DEFER_DESTROY"] = "1"
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", spec], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                timeout=420)

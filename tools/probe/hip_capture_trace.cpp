@@ -34,7 +34,35 @@ template <class F> static F real(const char* name) {
 }
 #define LOG(...) do { if (g_active) fprintf(out(), __VA_ARGS__); } while (0)
 
+// HIPCAPTRACE_DEFER_DESTROY=1: events destroyed while a capture is in progress are destroyed after hipStreamEndCapture instead
+// (test of the hypothesis that EndCapture touches events the application has already destroyed)
+#include <mutex>
+#include <vector>
+static std::mutex g_mu;
+static std::vector<hipEvent_t> g_deferred;
+static bool defer_destroy() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("HIPCAPTRACE_DEFER_DESTROY"); v = e && e[0] == '1'; }
+    return v;
+}
+
 extern "C" {
+hipError_t hipEventDestroy(hipEvent_t ev) {
+    static auto fn = real<hipError_t (*)(hipEvent_t)>("hipEventDestroy");
+    LOG("D %p tid %ld\n", (void*)ev, tid());
+    if (g_active && defer_destroy()) {
+        std::lock_guard<std::mutex> l(g_mu);
+        g_deferred.push_back(ev);
+        return hipSuccess;
+    }
+    return fn(ev);
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* ev, unsigned flags) {
+    static auto fn = real<hipError_t (*)(hipEvent_t*, unsigned)>("hipEventCreateWithFlags");
+    hipError_t e = fn(ev, flags);
+    LOG("C %p tid %ld flags %u\n", (void*)*ev, tid(), flags);
+    return e;
+}
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode mode) {
     static auto fn = real<hipError_t (*)(hipStream_t, hipStreamCaptureMode)>("hipStreamBeginCapture");
     g_active = 1;
@@ -48,6 +76,12 @@ hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
     hipError_t e = fn(s, g);
     LOG("E-done %d\n", (int)e);
     g_active = 0;
+    {
+        static auto destroy = real<hipError_t (*)(hipEvent_t)>("hipEventDestroy");
+        std::lock_guard<std::mutex> l(g_mu);
+        for (hipEvent_t ev : g_deferred) destroy(ev);
+        g_deferred.clear();
+    }
     return e;
 }
 hipError_t hipEventRecord(hipEvent_t ev, hipStream_t s) {
