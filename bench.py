@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--prio", default=None, help="(experiments) TrainStep.stream_priorities, comma separated")
     ap.add_argument("--min-pixels", type=int, default=None, help="(experiments) TrainStep.overlap_min_pixels")
     ap.add_argument("--layout", default=None, help="(experiments) TrainStep.stream_layout, e.g. 012301")
+    ap.add_argument("--graph-variant", default=None, help="(experiments) captured step: 'side-wgrad' (weight gradients on their side stream inside the capture too), "
+                                                          "'single-chain', 'one-stream'")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
     ap.add_argument("--force-launch", action="store_true", help="take the self-launch path (torch.distributed.run children) even for one GPU")
     ap.add_argument("--ddp-graph", action="store_true", help="data-parallel runs: also measure the hipGraph-captured step (RCCL inside the capture)")
@@ -273,6 +275,10 @@ def main():
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     if args.layout:
         faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = args.layout
+    if args.graph_variant == "side-wgrad":
+        faoctasr.TrainStep.capture_side_wgrad = True
+    elif args.graph_variant == "single-chain":
+        faoctasr.TrainStep.capture_two_chains = False
     if args.prio:
         faoctasr.TrainStep.stream_priorities = [int(v) for v in args.prio.split(",")]
     if args.min_pixels is not None:
@@ -386,7 +392,11 @@ def main():
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
     # (data-parallel: every rank captures and replays in lockstep, RCCL's kernels are graph nodes -- opt-in with --ddp-graph)
     graph_note = "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"
-    if args.graph_only or (not args.no_graph and distributed and args.ddp_graph):
+    if args.graph_only or (not args.no_graph and (not distributed or args.ddp_graph)):
+        # in this process (round 2 ran it in a child because hipStreamEndCapture crashed on some schedules; the cause -- forked
+        # streams waiting on each other, DESIGN.md 4.4 -- is removed from the schedule, so there is nothing left to isolate)
+        if args.graph_variant == "one-stream":
+            ts.overlap_wgrad = False
         gs = faoctasr.GraphedTrainStep(ts, real_A, real_B)
         for _ in range(2):
             gs.step(real_A, real_B)
@@ -402,19 +412,6 @@ def main():
         if args.graph_only:
             print(json.dumps({"hipgraph_step": extra["hipgraph_step"]}), flush=True)
             return
-    elif not args.no_graph and rank == 0 and not distributed:
-        # the secondary captured-step measurement runs in a child process: a fault inside the capture machinery (ROCm's
-        # hipStreamEndCapture has produced one during development) must not take the headline line with it
-        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--warmup", "2", "--batch", str(B),
-               "--size", str(H), "--precision", args.precision] + (["--no-overlap"] if args.no_overlap else [])
-        torch.cuda.empty_cache()             # the child needs the same working set: hand the cached blocks back first
-        try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            got = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
-            extra["hipgraph_step"] = got[-1]["hipgraph_step"] if got else {
-                "value": None, "note": "captured-step child exited with code %d: %s" % (r.returncode, r.stderr.decode(errors="replace").strip().splitlines()[-1:])}
-        except Exception as e:             # timeout, unparsable output
-            extra["hipgraph_step"] = {"value": None, "note": "captured-step child failed: %s" % type(e).__name__}
     if rank == 0 and world == 1 and not args.no_roofline:
         extra["roofline_hbm"] = hbm_kernels(device)
     if distributed:
