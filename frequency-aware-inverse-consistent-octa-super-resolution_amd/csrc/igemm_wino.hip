@@ -81,8 +81,12 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     wino_pack_block(w, up, g, blockIdx.x, gridDim.x);
 }
 
+// ksplit > 1 (grid z): the channel chunks are divided over `ksplit` blocks per (tile range, channel tile); each applies the (linear)
+// output transform to its partial sums and adds them into a zeroed y with fp32 atomics (no activation then; bias from split 0).
+// For grids that cannot fill the chip by tiles alone: the 32 x 32 maps at batch 1-2 (256 channels = 32 chunks).
 __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict__ x, const float* __restrict__ up,
-                                                         const float* __restrict__ bias, float* __restrict__ y, const WinoGeom g) {
+                                                         const float* __restrict__ bias, float* __restrict__ y, const WinoGeom g,
+                                                         const int ksplit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const U_lds = reinterpret_cast<float*>(smem);               // 3 x WN_U_FLOATS (weights are fetched two slabs ahead)
     float* const V_lds = U_lds + 3 * WN_U_FLOATS;                      // 2 x WN_V_FLOATS
@@ -101,13 +105,16 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     const long total_tiles = (long)g.N * tiles;
     if ((long)blockIdx.x >= total_tiles) return;
     const int mt = blockIdx.y;
-    const int nchunks = g.nchunks;
+    const int cps = (g.nchunks + ksplit - 1) / ksplit;                 // chunks per split
+    const int ch_base = (int)blockIdx.z * cps;
+    const int nchunks = g.nchunks - ch_base < cps ? g.nchunks - ch_base : cps;      // this block's chunks: ch_base .. ch_base + nchunks - 1
+    if (nchunks <= 0) return;
     const long chw = (long)g.IH * g.IW;
     // The persistent blocks run in step, and with one chunk order they would all stream the SAME 32 KiB slab of transformed weights
     // at the same moment -- 32 CUs of an XCD asking its L2 for the same lines.  The reduction over channels does not care about
     // order, so block b starts at chunk rot(b): consecutive blocks of one XCD (ids equal mod 8) get different slabs.
     const int rot = WINO_ROT ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
-    auto rot_chunk = [&](int ch) { const int c = ch + rot; return c >= nchunks ? c - nchunks : c; };
+    auto rot_chunk = [&](int ch) { const int c = ch + rot; return ch_base + (c >= nchunks ? c - nchunks : c); };
     auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {
         n = (int)(tl / tiles);
         const int rt = (int)(tl - (long)n * tiles);
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
             // rows, more than a consumer slab), plain loads pipeline.  Slab q+2 is stored during step q from registers loaded
             // during step q-1 (two slabs in flight per wave were tried: slower, the L2 -> CU path is the limit); the loop is peeled like the transform loop so that the compiler's vmcnt counts stay exact.
             const int w2 = (stid >> 6) & 1;                              // rows w2, w2+2, ... of the 32-row (1 KiB each) slab
-            const float* const usrc = up + (long)mt * nchunks * WN_U_FLOATS + w2 * 256 + lane * 4;
+            const float* const usrc = up + (long)mt * g.nchunks * WN_U_FLOATS + w2 * 256 + lane * 4;
             float* const udst = U_lds + w2 * 256 + lane * 4;
             f32x4w wr[16];
             auto load_u = [&](int ch) {
@@ -321,7 +328,8 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
     const int m_base = mt * WN_MT + 16 * wn + 4 * lk;                   // this lane's 4 output channels: the same for every tile
     float bv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (bias && m_base + r < g.M) ? bias[m_base + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bv[r] = (bias && blockIdx.z == 0 && m_base + r < g.M) ? bias[m_base + r] : 0.f;
+    const bool split = ksplit > 1;
 
     // Finished tiles are not stored at once: the 16 (float2) results of a lane wait in registers and leave two per slab
     // during the next tile's reduction.  All blocks of the persistent grid run in step, so storing at the tile boundary would
@@ -335,7 +343,10 @@ __global__ __launch_bounds__(512) void igemm_wino_kernel(const float* __restrict
         constexpr int nt = j >> 3, r = (j >> 1) & 3, a2 = j & 1;
         if ((pmask & (1u << j)) && (WINO_ABLATE & 32) == 0) {
             float* p = pbase + r * ohw + (long)(2 * nt + a2) * g.OW;
-            if (pair_ok) {
+            if (split) {
+                atomicAdd(p, pend[j][0]);
+                if (px1) atomicAdd(p + 1, pend[j][1]);
+            } else if (pair_ok) {
                 *reinterpret_cast<f32x2*>(p) = pend[j];
             } else {
                 p[0] = pend[j][0];
@@ -525,10 +536,25 @@ long wino_pack_floats_for(const IgemmGeom& f) {
     return (long)g.mtiles * g.nchunks * WN_U_FLOATS + 256;
 }
 
+// 1 = enough tiles without splitting; otherwise the number of channel splits that brings the grid to >= 128 blocks (each split keeps
+// >= 2 chunks, divides the chunk count, and the call has no activation), or 0 = leave the shape to the other kernels.
+// WHETHER this kernel takes a shape must not depend on FAOCTASR_CONV_NO_SPLIT_K: the packed-weight image is recorded (pack plans)
+// without that flag; under it the same shapes run unsplit here (one block owns an output element's whole reduction).
+static int wino_ksplit(const WinoGeom& g, int act) {
+    if (wino_worth(g)) return 1;
+    if (act != FAOCTASR_ACT_NONE) return 0;
+    const long blocks = wino_tiles(g) * g.mtiles;
+    for (int ks = 2; ks <= 16; ks *= 2)
+        if (g.nchunks % ks == 0 && g.nchunks / ks >= 2 && blocks * ks >= 128) return g_no_split_k ? 1 : ks;
+    return 0;
+}
+
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
              int wpack_state, hipStream_t s, PackJob* sink) {
     WinoGeom g;
-    if (!wino_geom_from(f, g) || !wino_worth(g)) return 0;
+    if (!wino_geom_from(f, g)) return 0;
+    const int ksplit = wino_ksplit(g, act);
+    if (ksplit == 0) return 0;
     g.act = act; g.slope = slope;
     if (sink) {
         sink->type = PACK_WINO; sink->w = w; sink->wp = wpack; sink->g.wino = g;
@@ -547,7 +573,8 @@ int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bi
     const size_t lds = (3 * (size_t)WN_U_FLOATS + 2 * (size_t)WN_V_FLOATS) * 4;
     auto k = igemm_wino_kernel;
     lds_optin((const void*)k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)nbx, g.mtiles), dim3(512), lds, s, x, wpack, bias, y, g);
+    if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess) return fail(FAOCTASR_EHIP, "memset y failed");
+    hipLaunchKernelGGL(k, dim3((unsigned)nbx, g.mtiles, (unsigned)ksplit), dim3(512), lds, s, x, wpack, bias, y, g, ksplit);
     const int rc = check_launch("igemm_wino");
     return rc == FAOCTASR_OK ? 1 : rc;
 }

@@ -484,6 +484,42 @@ def test_conv2d_winograd_matches_direct(fa):
     assert rel_l2(res[0][1], res[1][1]) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 32, 32, 256), (2, 256, 32, 32, 256), (1, 128, 30, 34, 96), (2, 128, 32, 32, 128)])
+def test_conv2d_winograd_split_k_small_grids(fa, shape):
+    """Grids too small to fill the chip by tiles (the 32 x 32 maps at batch 1-2: model.py:494-499 at train.py:173-176's batch 1) run
+    the Winograd kernel with the channel chunks split over grid z and fp32 atomics into a zeroed output.  Against the direct
+    kernel (forward with bias, input gradient), and -- same packed image, FAOCTASR_CONV_NO_SPLIT_K -- the unsplit form of the same
+    kernel, which must be bit-reproducible."""
+    N, C, H, W, M = shape
+    g = torch.Generator().manual_seed(70 + N + C + H)
+    x, w, b = dev(torch.randn(N, C, H, W, generator=g)), dev(torch.randn(M, C, 3, 3, generator=g) * 0.05), dev(torch.randn(M, generator=g))
+    cot = dev(torch.randn(N, M, H, W, generator=g))
+    res, routes = {}, {}
+    for prec in (0, 1):
+        fa.ops.conv_precision = prec
+        try:
+            xd = x.clone().requires_grad_(True)
+            out = fa.ops.conv2d(xd, w, b, 1, 1, False, None, 0.2)
+            routes[prec] = fa._lib.load().faoctasr_last_route()
+            out.backward(cot)
+            res[prec] = (out.detach(), xd.grad)
+        finally:
+            fa.ops.conv_precision = 0
+    assert routes[0] != routes[1], routes                  # the Winograd kernel really took the small grid
+    assert rel_l2(res[0][0], res[1][0]) < 5e-6
+    assert rel_l2(res[0][1], res[1][1]) < 5e-6
+    fa.ops.reproducible_forward = True
+    try:
+        with torch.no_grad():
+            r1 = fa.ops.conv2d(x, w, b, 1, 1, False, None, 0.2)
+            assert fa._lib.load().faoctasr_last_route() == routes[0]
+            r2 = fa.ops.conv2d(x, w, b, 1, 1, False, None, 0.2)
+    finally:
+        fa.ops.reproducible_forward = False
+    assert torch.equal(r1, r2)
+    assert rel_l2(r1, res[1][0]) < 5e-6
+
+
 SPLIT_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] // c[6] >= 24]
 
 

@@ -2,10 +2,10 @@
 # The rocprofv3 passes behind profiles/<tag>_*: kernel statistics, MFMA / LDS counters, FETCH_SIZE and WRITE_SIZE (one counter set
 # per pass, never together with a --sys/--hip trace), each of bench.py at the headline workload with the weight gradients on the
 # main stream (--no-overlap: a kernel's duration is then its own, as in bench.py's roofline leg).
-# usage, on the GPU box from the repo root:  bash tools/profile_round.sh r02      (raw output: gpurun_out/prof_<tag>/)
+# usage, on the GPU box from the repo root:  bash tools/profile_round.sh r03      (raw output: gpurun_out/prof_<tag>/)
 set -e
 R=$(pwd)
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp
