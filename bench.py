@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--prio", default=None, help="(experiments) TrainStep.stream_priorities, comma separated")
     ap.add_argument("--min-pixels", type=int, default=None, help="(experiments) TrainStep.overlap_min_pixels")
     ap.add_argument("--layout", default=None, help="(experiments) TrainStep.stream_layout, e.g. 012301")
+    ap.add_argument("--eager-chain-a-on-caller", action="store_true", help="(experiments) eager steps in the capturable chain arrangement")
     ap.add_argument("--graph-variant", default=None, help="(experiments) captured step: 'side-wgrad' (weight gradients on their side stream inside the capture too), "
                                                           "'single-chain', 'one-stream'")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the main stream (the form the per-kernel profiles are taken in)")
@@ -275,6 +276,8 @@ def main():
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     if args.layout:
         faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = args.layout
+    if args.eager_chain_a_on_caller:
+        faoctasr.TrainStep.eager_chain_A_forked = False
     if args.graph_variant == "side-wgrad":
         faoctasr.TrainStep.capture_side_wgrad = True
     elif args.graph_variant == "single-chain":

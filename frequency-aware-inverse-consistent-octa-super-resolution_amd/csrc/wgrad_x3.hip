@@ -261,9 +261,267 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One kernel ROW per block: the wide filters (7x7, pad 3, reflection or zero padding: model.py:451,473).  49 taps would need
+// 49 accumulator tiles per wave; a block takes the KW taps of one kernel row kh instead (KW accumulators, 112 registers at
+// KW = 7), so its input patch is just the 2 rows y0 + kh - pad, y0 + 1 + kh - pad of the 2-row pixel tile -- every input row is
+// still staged once per (tile, kh) pair that uses it, and dY is re-read by the KH blocks of a tile (L2).  Everything else is the
+// 3x3 kernel above: dY [m][pixel] for ds_read_b128, X transposed [pixel][32 channels] for ds_read_b64_tr_b16, hi/lo planes.
+// Reflection: a mirrored ROW is a redirected source row; a border chunk (image columns -4..-1 or W..W+3) is the neighbouring
+// chunk with its four pixels permuted (out[q] = in[4-q] left, in[2-q] right: pad <= 3, so the one pixel this cannot supply is
+// never read), exactly as wgrad_s1.hip does.
+constexpr int X3R_PROWS = 2;
+constexpr int X3R_PPIX = X3R_PROWS * X3_PCOLS;          // 80 pixels per channel block
+constexpr unsigned X3R_CB_BYTES = X3R_PPIX * 64;
+constexpr unsigned X3R_XPLANE = 2 * X3R_CB_BYTES;
+constexpr unsigned X3R_LDS = 2 * X3_DPLANE + 2 * X3R_XPLANE;      // 18432 + 20480 = 38912
+
+struct WgX3RowGeom {
+    int N, C, H, W, M, KH, pad, reflect;
+    long wsm, wsc;           // dW element strides of row m / channel c (KH*KW taps contiguous)
+    int tiles_x, tiles_y, tiles_per_block;
+    int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges (x KH kernel rows)
+};
+
+template <int KW>
+__global__ __launch_bounds__(256, 2) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                              const WgX3RowGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int mh = wave & 1, cb = wave >> 1;
+
+    const int per_slice = g.gx * g.gy * g.KH;
+    const int bid = blockIdx.x;
+    const int nfull = (g.slices / 8) * 8 * per_slice;
+    int slice, inner;
+    if (bid < nfull) {
+        const int xcd = bid & 7, k = bid >> 3;
+        inner = k % per_slice;
+        slice = (k / per_slice) * 8 + xcd;
+    } else {
+        const int r = bid - nfull;
+        inner = r % per_slice;
+        slice = (g.slices / 8) * 8 + r / per_slice;
+    }
+    const int kh = inner % g.KH;
+    const int rest = inner / g.KH;
+    const int c0 = (rest % g.gx) * 64, m0 = (rest / g.gx) * 64;
+    const long hw = (long)g.H * g.W;
+    const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
+    const long tile0 = (long)slice * g.tiles_per_block;
+    long tile1 = tile0 + g.tiles_per_block;
+    tile1 = tile1 < ntiles ? tile1 : ntiles;
+    if (tile0 >= tile1) return;
+
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned d_lds0 = lds0, x_lds0 = lds0 + 2 * X3_DPLANE;
+
+    unsigned dg_off[2], dl_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + 256 * i, m = it >> 3, ch = it & 7;
+        dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
+        dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
+    }
+    // X item i (2 per thread, 320 used): channel quad q8 of block cbs, patch row, chunk ck; lane bits: q8 fastest, then the chunk
+    unsigned xc_off[2], xl_off[2];
+    int x_row[2], x_ck[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + 256 * i;
+        const int q8 = it & 7, cklo = (it >> 3) & 7, rest2 = it >> 6;     // rest2 0..3: (cbs, row) with chunks 0..7; rest2 4: chunks 8, 9 of all (cbs, row)
+        int cbs, row, ck;
+        if (rest2 < 4) { cbs = rest2 & 1; row = rest2 >> 1; ck = cklo; }
+        else { cbs = cklo & 1; row = (cklo >> 1) & 1; ck = 8 + (cklo >> 2); }
+        const bool use = rest2 < 5;
+        x_row[i] = use ? row : -1;
+        x_ck[i] = ck;
+        xc_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw);      // channel part; row / column are resolved per tile (padding)
+        xl_off[i] = x_lds0 + (unsigned)cbs * X3R_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+    }
+
+    const unsigned a_addr = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
+    const int gi = lane & 15, q4 = gi >> 2, p4 = gi & 3, chh = (lane >> 4) & 1;
+    const unsigned b_addr = x_lds0 + (unsigned)cb * X3R_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
+
+    f32x16 acc[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int tn, ty, tx;
+    {
+        const long per_img = (long)g.tiles_y * g.tiles_x;
+        tn = (int)(tile0 / per_img);
+        const int r = (int)(tile0 - (long)tn * per_img);
+        ty = r / g.tiles_x;
+        tx = r - ty * g.tiles_x;
+    }
+
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const int y0 = ty * 2, x0 = tx * 32;
+        const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
+        const float* ximg = x + ((long)tn * g.C + c0) * hw;
+        if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
+
+        f32x4 dv[2][2], xv[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
+            dv[i][0] = *reinterpret_cast<const f32x4*>(p);
+            dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
+        }
+        int flip[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy = y0 + x_row[i] + kh - g.pad, gx0 = x0 - 4 + 4 * x_ck[i];
+            bool ok = x_row[i] >= 0;
+            flip[i] = 0;
+            if (g.reflect) {
+                iy = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
+                if (gx0 < 0) { gx0 = 0; flip[i] = 1; }
+                else if (gx0 >= g.W) { gx0 = g.W - 4; flip[i] = 2; }
+            } else {
+                ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ximg + (long)c * hw + (long)iy * g.W + gx0) + xc_off[i]);
+            }
+        }
+        if (tile != tile0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            split2(dv[i][0][0], dv[i][0][1], h0, l0);
+            split2(dv[i][0][2], dv[i][0][3], h1, l1);
+            split2(dv[i][1][0], dv[i][1][1], h2, l2);
+            split2(dv[i][1][2], dv[i][1][3], h3, l3);
+            const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+            const unsigned da = dl_off[i];
+            asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (x_row[i] < 0) continue;
+            const unsigned xa = xl_off[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                                // mirrored border chunks (reflection only)
+                const f32x4 v = xv[i][c];
+                const f32x4 l = {v[0], v[3], v[2], v[1]}, r = {v[2], v[1], v[0], v[3]};
+                xv[i][c] = flip[i] == 1 ? l : (flip[i] == 2 ? r : v);
+            }
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                unsigned h0, h1, l0, l1;
+                split2(xv[i][0][px], xv[i][1][px], h0, l0);
+                split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3R_XPLANE) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- contraction: 4 k-blocks of 16 pixels x KW taps x 3 split products ----
+        x3_static_for<0, 4>([&](auto kc) {
+            constexpr int kb = decltype(kc)::value;
+            constexpr unsigned a_imm = 2u * (unsigned)((kb >> 1) * 32 + 16 * (kb & 1));
+            bf16x8 a_hi, a_lo;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_hi) : "v"(a_addr), "n"(a_imm));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_lo) : "v"(a_addr), "n"(a_imm + X3_DPLANE));
+            bf16x4 bh[KW][2], bl[KW][2];
+            x3_static_for<0, KW>([&](auto wc) {
+                constexpr int kw = decltype(wc)::value;
+                // pixel of k index j: patch row kb >> 1, column 16 (kb & 1) + j + kw + (4 - pad); pad = (KW - 1) / 2
+                constexpr unsigned imm = (unsigned)((kb >> 1) * X3_PCOLS + 16 * (kb & 1) + kw + (4 - (KW - 1) / 2)) * 64u;
+                const unsigned ba = b_addr;                              // (asm operands cannot name a captured variable / array element)
+                bf16x4 h0, h1, l0, l1;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h0) : "v"(ba), "n"(imm));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h1) : "v"(ba), "n"(imm + 4 * 64));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l0) : "v"(ba), "n"(imm + X3R_XPLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l1) : "v"(ba), "n"(imm + 4 * 64 + X3R_XPLANE));
+                bh[kw][0] = h0; bh[kw][1] = h1; bl[kw][0] = l0; bl[kw][1] = l1;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_hi), "+v"(a_lo));
+            x3_static_for<0, KW>([&](auto wc) {
+                constexpr int kw = decltype(wc)::value;
+                bf16x4 h0 = bh[kw][0], h1 = bh[kw][1], l0 = bl[kw][0], l1 = bl[kw][1];
+                asm volatile("" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));      // the fragments are ordered behind the wait
+                bh[kw][0] = h0; bh[kw][1] = h1; bl[kw][0] = l0; bl[kw][1] = l1;
+            });
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const bf16x8 b_hi = __builtin_shufflevector(bh[kw][0], bh[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 b_lo = __builtin_shufflevector(bl[kw][0], bl[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                f32x16& d = acc[kw];
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, d, 0, 0, 0);
+            }
+        });
+    }
+
+    // ---- epilogue: [m][channel] per tap -> dW[m][c][kh][0..KW) through LDS, atomics in runs of KW floats per channel ----
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem) + wave * (8 * 32 * KW);
+    const long col_base = (long)(c0 + cb * 32) * g.wsc + (long)kh * KW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < KW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * KW + t] = acc[t][4 * j + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < (8 * 32 * KW + 63) / 64; ++i) {
+            const int e = lane + 64 * i;                                 // element of [8 rows][32 channels][KW taps]
+            if (e < 8 * 32 * KW) {
+                const int row = e / (32 * KW), rem = e - row * (32 * KW), ch = rem / KW, t = rem - ch * KW;
+                atomicAdd(dw + (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + (long)ch * g.wsc + t, stage[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW, int pad,
+                               int reflect, long wsm, long wsc, hipStream_t s) {
+    if (KH != 7 || KW != 7 || pad != 3) return 0;                        // (KW is a template parameter; 7x7 is what the path has)
+    if ((C & 63) || (M & 63) || (IW & 31) || (IH & 1) || wsc != (long)KH * KW) return 0;
+    if (reflect && (IH <= pad || IW < 8)) return 0;
+    if ((long)64 * IH * IW >= (1L << 29)) return 0;
+    WgX3RowGeom g;
+    g.N = N; g.C = C; g.H = IH; g.W = IW; g.M = M; g.KH = KH; g.pad = pad; g.reflect = reflect; g.wsm = wsm; g.wsc = wsc;
+    g.tiles_x = IW / 32; g.tiles_y = IH / 2;
+    g.gx = C / 64; g.gy = M / 64;
+    const long ntiles = (long)N * g.tiles_y * g.tiles_x;
+    long slices = 512 / ((long)g.gx * g.gy * KH);
+    if (slices < 1) slices = 1;
+    if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
+    g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
+    g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    auto k = wgrad_x3_row_kernel<7>;
+    lds_optin((const void*)k, X3R_LDS);
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * KH * g.slices)), dim3(256), X3R_LDS, s, x, dy, dw, g);
+    const int rc = check_launch("wgrad_x3_row");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
 // returns 1 when launched, 0 when the shape is left to the fp32 kernels, <0 on error.  dw zeroed / accumulating, as elsewhere.
 int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
+    if (stride == 1 && KH == 7 && OH == IH && OW == IW) return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, KH, KW, pad, reflect, wsm, wsc, s);
     if (stride != 1 || KH != 3 || KW != 3 || pad != 1 || reflect || OH != IH || OW != IW) return 0;
     if ((C & 63) || (M & 63) || (OW & 31) || (OH & 1) || wsc != 9) return 0;
     if ((long)64 * IH * IW >= (1L << 29)) return 0;                      // 32-bit byte offsets inside a 64-channel slab

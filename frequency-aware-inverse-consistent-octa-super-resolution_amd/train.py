@@ -191,6 +191,10 @@ class TrainStep:
     overlap_min_pixels = 2 * 256 * 256
     #: the two-chain generator schedule inside a hipGraph capture as well (False: the captured step keeps the single-chain form)
     capture_two_chains = True
+    #: eager steps: chain A on the forked stream and chain B on the caller's (round 2's arrangement, which a capture cannot hold):
+    #: 109.7 against 111.4 ms per step at batch 8 (same box, two runs each) -- the capturable arrangement puts chain B's backward and the
+    #: discriminators' update on streams that share more
+    eager_chain_A_forked = True
     #: inside a hipGraph capture: weight gradients on their side stream (True) or in line with the backward chain (False).  Every
     #: weight gradient on the side stream is a fork + join in the graph (~250 per step), which the runtime's graph executor pays for
     #: at replay: 121.3 ms per step against 115.6 in line (batch 8, MI355X; eager streams: 110.7)
@@ -488,6 +492,114 @@ class TrainStep:
                                {k: (extra_A[k].detach(), v) for k, v in extra_B.items()})
         return o, L, root
 
+    def _generators_two_chains_eager(self, real_A, real_B):
+        """Round 2's arrangement of ``_generators_two_chains``, kept for eager (un-captured) steps when ``eager_chain_A_forked`` is set:
+        chain A on the forked stream ``_aba`` and chain B on the caller's.  It cannot be captured (its two forked streams wait on each
+        other: see ``_generators_two_chains``); outside a capture that is harmless.
+
+        The generator phase (train.py:173-236) as two chains on two streams:
+
+            chain A (stream ``_aba``):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
+            chain B (main stream)    :  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
+            identity passes (``_idt``) and the frozen discriminator passes (branch streams) as in ``forward_generators``
+
+        Chain A's loss terms depend on nothing chain B computes, so its backward -- a third of the generators' backward work -- runs
+        under chain B's forward.  Each network's three passes keep the reference's order (A2B: real_A, real_B, fake_A; B2A: real_A,
+        fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence.  Returns (o, L, root):
+        ``root`` is what is left to back-propagate (chain B's terms)."""
+        G_A2B, G_B2A, w = self.netG_A2B, self.netG_B2A, self.w
+        ones, _ = self.targets(real_A.shape[0])
+        main = torch.cuda.current_stream(self.device)
+        X, I, side = self._aba, self._idt, self._side
+        cA, cB = self._branch
+        o, L = {}, {}
+        hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the main stream
+        hfB, lfB = ops.freq_split(real_B, 5, 14)
+        ev_in = _Mark(main)
+        for t in (hfA, lfA, hfB, lfB, real_A, real_B):
+            t.record_stream(X)
+            t.record_stream(I)
+
+        def identity(net, first, second, real, key, after):
+            _after(I, ev_in)
+            _after(I, after)
+            with torch.cuda.stream(I):
+                _, _, o[key] = net(first, second)
+                ev = _Mark(I)
+                term = ops.l1_loss(real, o[key], w["beta2"])
+                ops.wgrad_stream = side
+                try:
+                    term.backward()
+                finally:
+                    ops.wgrad_stream = None
+            o[key].record_stream(main)
+            term.record_stream(main)
+            return ev, term.detach()
+
+        def critic(net, fake, st, src):
+            _wait(st, src)
+            fake.record_stream(st)
+            with torch.cuda.stream(st):
+                pred = net(fake)
+            return pred, _Mark(st)
+
+        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                   # B2A pass 1
+        _after(X, ev_in)
+        with torch.cuda.stream(X):
+            _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                  # A2B pass 1
+            ev_a2b_1 = _Mark(X)
+            o["hf_feature_A"] = hf_feature_A.detach()
+            pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, X)
+            hf, lf = ops.freq_split(o["fake_B"], 5, 14)
+            _after(X, ev_idt_A)
+            o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                # B2A pass 2
+            ev_b2a_2 = _Mark(X)
+            _after(X, ev_pred_B)                 # (layout "001212": chain A and critic B share a stream -- no wait is issued then)
+            pred_B.record_stream(X)
+            L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
+            L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
+            chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
+            extra_A = self._extension_terms(o["recovered_A"], real_A)
+            for k, v in extra_A.items():
+                chain_A = chain_A + v
+            ops.wgrad_stream = side
+            try:
+                chain_A.backward()
+            finally:
+                ops.wgrad_stream = None
+        _after(main, ev_b2a_2)
+        hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                      # B2A pass 3
+        o["hf_feature_B"] = hf_feature_B.detach()
+        pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, main)
+        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2
+        hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        _after(main, ev_idt_B)
+        _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                    # A2B pass 3
+        _after(main, ev_pred_A)
+        pred_A.record_stream(main)
+        L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
+        L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
+            ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
+        root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+        done = None
+        for k, v in self._extension_terms(o["recovered_B"], real_B).items():        # opt-in SSIM / wavelet-HF terms: one half per chain
+            root = root + v
+            extra_A[k].record_stream(main)
+            L[k] = v + extra_A[k].detach()
+            done = extra_A[k].detach() if done is None else done + extra_A[k].detach()
+        for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
+            L[k].record_stream(main)
+            L[k] = L[k].detach()
+        for k in ("fake_B", "hf_feature_A", "hf_feature_recovered_A", "recovered_A"):
+            o[k].record_stream(main)
+        L["loss_idt"] = idt_A + idt_B
+        o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
+        L["loss_G"] = root.detach() + L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"]
+        if done is not None:
+            L["loss_G"] = L["loss_G"] + done
+        self._chain_B_terms = None            # this arrangement has already formed every total on the caller's stream
+        return o, L, root
+
     def _extension_terms(self, rec, real):
         """One image pair's share of the opt-in terms of ``generator_loss`` (SSIM: train.py:234; wavelet-HF L1)."""
         t = {}
@@ -593,7 +705,9 @@ class TrainStep:
         # communicator, depends on the batch shape alone, never on rank-local cache state)
         multi = streams
         two_chains = multi and (self.capture_two_chains or not torch.cuda.is_current_stream_capturing())
-        if two_chains:
+        if two_chains and self.eager_chain_A_forked and not torch.cuda.is_current_stream_capturing():
+            o, L, root = self._generators_two_chains_eager(real_A, real_B)
+        elif two_chains:
             o, L, root = self._generators_two_chains(real_A, real_B)
         else:
             o = self.forward_generators(real_A, real_B, self._branch if multi else None, (self._idt, self._side) if multi else None)
@@ -624,7 +738,7 @@ class TrainStep:
                     # there), the frozen discriminator passes' input gradients on the branch streams
                     _join(torch.cuda.current_stream(self.device), (self._idt, self._aba) + tuple(self._branch))
                 ops.join_wgrad_stream(side_G)
-            if two_chains:                       # chain B's terms were computed on its stream: the total is formed after the join
+            if two_chains and self._chain_B_terms is not None:     # chain B's terms were computed on its stream: the totals are formed after the join
                 root_B, rest, done, halves = self._chain_B_terms
                 L["loss_G"] = root_B.detach() + rest if done is None else root_B.detach() + rest + done
                 for k, (ha, hb) in halves.items():

@@ -86,6 +86,8 @@ CONV_CASES = [
     (2, 2, 36, 72, 42, 4, 2, 1, False, True, None),           # C = 2, M not a multiple of the channel group
     (1, 4, 8, 8, 8, 4, 2, 1, False, False, None),             # C = 4, a map smaller than one tile
     (8, 1, 256, 256, 64, 4, 2, 1, False, False, "lrelu"),     # the benchmark's discriminator stem
+    (2, 64, 32, 64, 64, 7, 1, 3, True, False, None),          # 7x7 reflect, 2 tiles wide: both mirrored border chunks and mirrored rows (bf16x3: wgrad_x3_row_kernel)
+    (1, 128, 34, 32, 64, 7, 1, 3, False, True, None),         # 7x7 zero padding, two 64-channel slabs
 ]
 
 
@@ -547,7 +549,8 @@ def test_conv2d_bf16x3(fa, case):
     assert rel_l2(out, ref) < 3e-5
     assert rel_l2(xd.grad, xr.grad) < 3e-5
     # the weight gradient: split-precision kernel (route 15) on the stride-1 3x3 layers with C, M % 64 == 0, W % 32 == 0, even H
-    x3 = k == 3 and s == 1 and p == 1 and not reflect and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0
+    # ... and on the 7x7 pad-3 layers, reflection or zero padding, one kernel row per block (wgrad_x3_row_kernel)
+    x3 = s == 1 and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0 and ((k == 3 and p == 1 and not reflect) or (k == 7 and p == 3))
     assert rel_l2(wd.grad, wr.grad) < 3e-5
     # which kernel took it (the route is per calling thread, autograd's backward runs on another one: ask the C ABI directly)
     from faoctasr._lib import call, ptr, stream_ptr
