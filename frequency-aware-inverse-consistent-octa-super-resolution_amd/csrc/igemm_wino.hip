@@ -567,7 +567,10 @@ int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bi
         if (rc) return rc;
     }
     const long tiles = wino_tiles(g);
-    long nbx = 256 / g.mtiles;
+#ifndef WINO_CUS
+#define WINO_CUS 256       // blocks of the persistent grid (experiment: fewer than the chip's 256 CUs, tools/variants.py)
+#endif
+    long nbx = WINO_CUS / g.mtiles;
     nbx = nbx < 1 ? 1 : nbx;
     nbx = nbx > tiles ? tiles : nbx;
     const size_t lds = (3 * (size_t)WN_U_FLOATS + 2 * (size_t)WN_V_FLOATS) * 4;

@@ -223,29 +223,36 @@ __device__ __forceinline__ void ss_static_for(F&& f) {
 
 // planar scalars: v_pk_fma_f32 has the FLOP rate of two v_fma_f32 on this chip, and the packed form cost ~85 v_mov per row to
 // keep its operands in aligned register pairs (ISA count of the first version)
-struct Mom { float ma, mb, maa, mbb, mab; };                             // mu_a, mu_b, E a^2, E b^2, E ab
+// FOUR filtered maps, not five: SSIM needs sigma_a^2 + sigma_b^2 only as a sum, so E a^2 and E b^2 travel as one map
+// E (a^2 + b^2) (20 % fewer filter FMAs in the forward and -- its two partial derivatives being equal -- in the backward)
+struct Mom { float ma, mb, mss, mab; };                                  // mu_a, mu_b, E (a^2 + b^2), E ab
 
 // row-filtered moments of the lane's two columns from the 12 staged pairs
 __device__ __forceinline__ void row_moments(const f2 (&v)[12], const Taps& tp, Mom (&out)[2]) {
-    float aa[12], bb[12], ab[12];
+    float ss[12], ab[12];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) { aa[q] = v[q][0] * v[q][0]; bb[q] = v[q][1] * v[q][1]; ab[q] = v[q][0] * v[q][1]; }
+    for (int q = 0; q < 12; ++q) { ss[q] = __builtin_fmaf(v[q][1], v[q][1], v[q][0] * v[q][0]); ab[q] = v[q][0] * v[q][1]; }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        Mom s = {0.f, 0.f, 0.f, 0.f, 0.f};
+        Mom s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             const float g = tp.g[k];
             s.ma += g * v[j + k][0]; s.mb += g * v[j + k][1];
-            s.maa += g * aa[j + k]; s.mbb += g * bb[j + k]; s.mab += g * ab[j + k];
+            s.mss += g * ss[j + k]; s.mab += g * ab[j + k];
         }
         out[j] = s;
     }
 }
 
-__device__ __forceinline__ Mom mom_zero() { return Mom{0.f, 0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ Mom mom_zero() { return Mom{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void mom_axpy(Mom& acc, float g, const Mom& h) {
-    acc.ma += g * h.ma; acc.mb += g * h.mb; acc.maa += g * h.maa; acc.mbb += g * h.mbb; acc.mab += g * h.mab;
+    acc.ma += g * h.ma; acc.mb += g * h.mb; acc.mss += g * h.mss; acc.mab += g * h.mab;
+}
+// the same value as ssim_point(m1, m2, e11, e22, e12) with e11 + e22 given as one number
+__device__ __forceinline__ float ssim_point_sum(float m1, float m2, float ess, float e12) {
+    const float s12 = e12 - m1 * m2, mm = m1 * m1 + m2 * m2;
+    return ((2.f * m1 * m2 + C1) * (2.f * s12 + C2)) / ((mm + C1) * ((ess - mm) + C2));
 }
 
 // stage one input row of the strip in the wave's LDS row and fetch the lane's 12 pairs.  `cur` = this lane's two columns of
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
                         Mom m = mom_zero();
 #pragma unroll
                         for (int k = 0; k < 11; ++k) mom_axpy(m, tp.g[k], ring[(j + 2 + k) % RING][c]);
-                        if (xc + c < W) local += ssim_point(m.ma, m.mb, m.maa, m.mbb, m.mab);
+                        if (xc + c < W) local += ssim_point_sum(m.ma, m.mb, m.mss, m.mab);
                     }
                 }
             }
@@ -347,18 +354,18 @@ __global__ __launch_bounds__(256) void ssim_fwd_slide_kernel(const float* __rest
 }
 
 
-// Backward, sliding form.  Two separable filters in sequence per wave: (1) moments -> the five partial-derivative maps
-// f = d ssim / d (mu_a, mu_b, E a^2, E b^2, E ab) at the rows that have left the first ring; (2) the same window applied to f
-// (the window is symmetric, so the adjoint of the zero-padded correlation is itself) through a second exchange + ring; then
-// da = g (F0 + 2 a F2 + b F4), db = g (F1 + 2 b F3 + a F4).  A wave computes f on its 128 lane columns and gradients on the
+// Backward, sliding form.  Two separable filters in sequence per wave: (1) moments -> the partial-derivative maps
+// f = d ssim / d (mu_a, mu_b, E a^2 = E b^2 [one map: the two are equal], E ab) at the rows that have left the first ring; (2) the
+// same window applied to f (the window is symmetric, so the adjoint of the zero-padded correlation is itself) through a second
+// exchange + ring; then da = g (F0 + 2 a F2 + b F4), db = g (F1 + 2 b F2 + a F4).  A wave computes f on its 128 lane columns and gradients on the
 // inner 116 (strips overlap by 12 columns, row segments by 20 rows); one wave per 64-thread block (two 11-row rings = 220 VGPRs).
 constexpr int SB_OUT = 116, SB_LEFT = 6;                                 // output columns x0+6 .. x0+121 of the 128 lane columns
-struct F5 { float f0, f1, f2_, f3, f4; };
+struct F5 { float f0, f1, f2_, f4; };                                    // (four maps; the name is historical)
 
 __device__ __forceinline__ F5 ssim_partials(const Mom& m) {
     const float m1 = m.ma, m2 = m.mb;
-    const float s11 = m.maa - m1 * m1, s22 = m.mbb - m2 * m2, s12 = m.mab - m1 * m2;
-    const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
+    const float mm = m1 * m1 + m2 * m2, s12 = m.mab - m1 * m2;
+    const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = mm + C1, B2 = (m.mss - mm) + C2;
     const float rB1 = 1.f / B1, rB2 = 1.f / B2;                          // two divisions instead of seven
     const float inv = rB1 * rB2;
     const float S = A1 * A2 * inv;
@@ -366,20 +373,21 @@ __device__ __forceinline__ F5 ssim_partials(const Mom& m) {
     f.f0 = (2.f * m2 * (A2 - A1)) * inv - S * (2.f * m1 * rB1 - 2.f * m1 * rB2);
     f.f1 = (2.f * m1 * (A2 - A1)) * inv - S * (2.f * m2 * rB1 - 2.f * m2 * rB2);
     f.f2_ = -S * rB2;
-    f.f3 = f.f2_;
     f.f4 = 2.f * A1 * inv;
     return f;
 }
-__device__ __forceinline__ F5 f5_zero() { return F5{0.f, 0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ F5 f5_zero() { return F5{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void f5_axpy(F5& acc, float g, const F5& h) {
-    acc.f0 += g * h.f0; acc.f1 += g * h.f1; acc.f2_ += g * h.f2_; acc.f3 += g * h.f3; acc.f4 += g * h.f4;
+    acc.f0 += g * h.f0; acc.f1 += g * h.f1; acc.f2_ += g * h.f2_; acc.f4 += g * h.f4;
 }
 
-__global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
+// (two waves per SIMD: with four maps the two 11-row rings + the exchange leave the kernel 8 registers over 256; the compiler is asked
+// to fit, which it does without scratch)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssim_bwd_slide_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
                                                             int gN, float gscale, float* __restrict__ da, float* __restrict__ db, int planes, int C,
                                                             int H, int W, int nstrips, int nseg, int seg_rows, const Taps tp) {
     __shared__ __attribute__((aligned(16))) f2 rowbuf[SL_PAIRS];
-    __shared__ __attribute__((aligned(16))) f2 fbuf[(SL_COLS + 12) * 3];    // per column (f0,f1),(f2,f3),(f4,-); index i <-> column x0 - 6 + i
+    __shared__ __attribute__((aligned(16))) f2 fbuf[(SL_COLS + 12) * 2];    // per column (f0,f1),(f2,f4): 16 bytes; index i <-> column x0 - 6 + i
     const int lane = threadIdx.x;
     SlideItem it;
     {
@@ -454,43 +462,33 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
                 // exchange f across the lanes: column index i = 6 + 2 lane + c
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    f2* dst = fbuf + (SB_LEFT + 2 * lane + c) * 3;
-                    dst[0] = f2{f[c].f0, f[c].f1}; dst[1] = f2{f[c].f2_, f[c].f3}; dst[2] = f2{f[c].f4, 0.f};
+                    f2* dst = fbuf + (SB_LEFT + 2 * lane + c) * 2;
+                    dst[0] = f2{f[c].f0, f[c].f1}; dst[1] = f2{f[c].f2_, f[c].f4};
                 }
                 if (lane < 6) {                                         // columns x0-6 .. x0-1 and x0+128 .. x0+133 never hold map values
-                    f2* z0 = fbuf + lane * 3;
-                    f2* z1 = fbuf + (SB_LEFT + SL_COLS + lane) * 3;
-                    z0[0] = z0[1] = z0[2] = f2{0.f, 0.f};
-                    z1[0] = z1[1] = z1[2] = f2{0.f, 0.f};
+                    f2* z0 = fbuf + lane * 2;
+                    f2* z1 = fbuf + (SB_LEFT + SL_COLS + lane) * 2;
+                    z0[0] = z0[1] = f2{0.f, 0.f};
+                    z1[0] = z1[1] = f2{0.f, 0.f};
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // the lane's output columns need f columns (2 lane + c) - 5 .. + 5 -> indices 2 lane + 1 .. 2 lane + 12
-                F5 w[12];
+                // the lane's output columns need f columns (2 lane + c) - 5 .. + 5 -> indices 2 lane + 1 .. 2 lane + 12: each column is one
+                // 16-byte read, consumed at once by both outputs (no 12-column register array)
                 {
                     typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v* src = reinterpret_cast<const f4v*>(fbuf + (2 * lane) * 3);     // 48 * lane bytes: 16-byte aligned
-                    float t[13 * 6];
-#pragma unroll
-                    for (int q = 0; q < 20; ++q) {                       // columns 2 lane .. 2 lane + 12 (13 columns x 6 floats = 78 floats)
-                        const f4v r = src[q];
-                        if (4 * q + 0 < 78) t[4 * q + 0] = r[0];
-                        if (4 * q + 1 < 78) t[4 * q + 1] = r[1];
-                        if (4 * q + 2 < 78) t[4 * q + 2] = r[2];
-                        if (4 * q + 3 < 78) t[4 * q + 3] = r[3];
-                    }
+                    const f4v* src = reinterpret_cast<const f4v*>(fbuf + (2 * lane) * 2);     // 32 * lane bytes
+                    F5 acc0 = f5_zero(), acc1 = f5_zero();
 #pragma unroll
                     for (int q = 0; q < 12; ++q) {
-                        w[q] = F5{t[6 * (q + 1)], t[6 * (q + 1) + 1], t[6 * (q + 1) + 2], t[6 * (q + 1) + 3], t[6 * (q + 1) + 4]};
+                        const f4v r = src[q + 1];
+                        const F5 wq = F5{r[0], r[1], r[2], r[3]};
+                        if (q < 11) f5_axpy(acc0, tp.g[q], wq);
+                        if (q >= 1) f5_axpy(acc1, tp.g[q - 1], wq);
                     }
-                }
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    F5 acc = f5_zero();
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) f5_axpy(acc, tp.g[k], w[c + k]);
-                    ring2[j][c] = acc;
+                    ring2[j][0] = acc0;
+                    ring2[j][1] = acc1;
                 }
                 // stage 2 column pass -> gradient row yo2
                 if (yo2 >= it.r0 && cout) {                              // (yo2 < r1 by construction of y_last)
@@ -501,7 +499,7 @@ __global__ __launch_bounds__(64) void ssim_bwd_slide_kernel(const float* __restr
 #pragma unroll
                         for (int k = 0; k < 11; ++k) f5_axpy(acc, tp.g[k], ring2[(j + 1 + k) % 11][c]);
                         oa[c] = gv * (acc.f0 + 2.f * av[c] * acc.f2_ + bv[c] * acc.f4);
-                        ob[c] = gv * (acc.f1 + 2.f * bv[c] * acc.f3 + av[c] * acc.f4);
+                        ob[c] = gv * (acc.f1 + 2.f * bv[c] * acc.f2_ + av[c] * acc.f4);
                     }
                     const long off = (long)it.plane * H * W + (long)yo2 * W + xc;
                     if (da) *reinterpret_cast<f2*>(da + off) = oa;
