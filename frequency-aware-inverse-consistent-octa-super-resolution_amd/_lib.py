@@ -100,7 +100,16 @@ def load():
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """hipStream_t of the calling thread's current stream on its current device.  ``torch.cuda.current_stream()`` builds a Stream
+    object through three Python layers (7.5 us a call, ~800 calls per step and thread: 6 ms of a 36 ms batch-1 step by cProfile,
+    tools/host_profile.py); the raw accessors are two C calls."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -118,19 +127,24 @@ def ptr(t):
 launch_timer = None
 
 
+_fn = {}
+
+
 def call(name, *args):
-    lib = _lib or load()
+    fn = _fn.get(name)
+    if fn is None:
+        fn = _fn[name] = getattr(_lib or load(), "faoctasr_" + name)
     t = launch_timer
     if t is not None and name in t.names:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        rc = getattr(lib, "faoctasr_" + name)(*args)
+        rc = fn(*args)
         e.record()
-        t.add(name, args, s, e, lib.faoctasr_last_route())
+        t.add(name, args, s, e, _lib.faoctasr_last_route())
     else:
-        rc = getattr(lib, "faoctasr_" + name)(*args)
+        rc = fn(*args)
     if rc != 0:
-        raise KernelError("faoctasr_%s failed (%d): %s" % (name, rc, lib.faoctasr_last_error().decode()))
+        raise KernelError("faoctasr_%s failed (%d): %s" % (name, rc, _lib.faoctasr_last_error().decode()))
 
 
 _ws = {}
@@ -138,7 +152,8 @@ _ws = {}
 
 def workspace(device, nfloats):
     """Per-(device, stream) scratch reused by the stream-ordered reduction kernels."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)

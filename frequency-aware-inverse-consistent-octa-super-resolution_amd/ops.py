@@ -354,7 +354,8 @@ class _BatchNormTrain(Function):
         y = torch.empty_like(x)
         stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ws = _lib.workspace(x.device, C * 128)
-        call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(stats[0]), ptr(stats[1]),
+        sp = stats.data_ptr()                   # (row views cost ~3 us each on the host: 243 calls per step)
+        call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), sp, sp + 4 * C,
              ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr())
         # the backward takes the ReLU / LeakyReLU mask from x when there was no residual (faoctasr.h): y is then not kept by this node
         need_y = act == ACT_TANH or (act and residual is not None)
@@ -387,7 +388,8 @@ class _BatchNormTrain(Function):
         if has_res and ctx.needs_input_grad[3]:
             dres = torch.empty_like(x) if act else dy
         ws = _lib.workspace(x.device, C * 128)
-        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx),
+        sp = stats.data_ptr()
+        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), sp, sp + 4 * C, ptr(dx),
              ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
              N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
