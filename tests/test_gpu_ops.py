@@ -486,6 +486,32 @@ def test_conv2d_winograd_matches_direct(fa):
     assert rel_l2(res[0][1], res[1][1]) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 128, 128, 64), (5, 24, 70, 100, 80), (8, 16, 96, 99, 64), (8, 20, 96, 96, 64), (2, 64, 256, 256, 64)])
+@pytest.mark.parametrize("act", [None, "lrelu"])
+def test_conv2d_winograd_large_grids(fa, shape, act):
+    """The Winograd kernel on large grids (every block walks several tiles of its persistent sequence), against the direct kernel:
+    forward with bias and activation, input gradient; shapes with ragged tile rows / columns, a partial channel tile, odd width,
+    a channel count that is not a multiple of the chunk, and the benchmark's 64 -> 64 layer at 256 x 256 (model.py:412-414).
+    (Written for the 64-tile experiment of tools/experiments/igemm_wino64.hip, which passed it; kept for the product kernel.)"""
+    N, C, H, W, M = shape
+    g = torch.Generator().manual_seed(90 + N + C + H + W)
+    x, w, b = dev(torch.randn(N, C, H, W, generator=g)), dev(torch.randn(M, C, 3, 3, generator=g) * 0.05), dev(torch.randn(M, generator=g))
+    cot = dev(torch.randn(N, M, H, W, generator=g))
+    res = {}
+    for prec in (0, 1):
+        fa.ops.conv_precision = prec
+        try:
+            xd = x.clone().requires_grad_(True)
+            out = fa.ops.conv2d(xd, w, b, 1, 1, False, act, 0.2)
+            out.backward(cot)
+            res[prec] = (out.detach(), xd.grad)
+        finally:
+            fa.ops.conv_precision = 0
+    assert not torch.equal(res[0][0], res[1][0])
+    assert rel_l2(res[0][0], res[1][0]) < 5e-6
+    assert rel_l2(res[0][1], res[1][1]) < 5e-6
+
+
 @pytest.mark.parametrize("shape", [(1, 256, 32, 32, 256), (2, 256, 32, 32, 256), (1, 128, 30, 34, 96), (2, 128, 32, 32, 128)])
 def test_conv2d_winograd_split_k_small_grids(fa, shape):
     """Grids too small to fill the chip by tiles (the 32 x 32 maps at batch 1-2: model.py:494-499 at train.py:173-176's batch 1) run
