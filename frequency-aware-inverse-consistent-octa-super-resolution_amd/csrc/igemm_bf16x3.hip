@@ -26,6 +26,10 @@ namespace faoctasr {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef SP_ABLATE
+#define SP_ABLATE 0               // diagnostics (tools/variants.py): 1 no weight DMA, 2 no patch loads, 4 no split / patch stores, 8 no MFMA, 16 no output stores
+#endif
+
 constexpr int SP_MT = 64;         // output channels per block
 constexpr int SP_NPI = 6;         // (pixel, h) items staged per thread
 
@@ -111,6 +115,9 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
         const unsigned cstep = 4u * (unsigned)chw;
         const float* xin = x;
         float pv[NPI][8];
+        if constexpr ((SP_ABLATE & 2) != 0)
+            for (int i = 0; i < NPI; ++i)
+                for (int j = 0; j < 8; ++j) pv[i][j] = (float)(tid + i + j);
         auto compute_poff = [&](long tl) {
             int n, ty, tx;
             tile_coords(tl, n, ty, tx);
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
             }
         };
         auto load_patch = [&](int grp) {
+            if constexpr ((SP_ABLATE & 2) != 0) return;
             const long bytes = (long)(g.C - grp * 16) * chw * 4;
             const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
                                                                (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                     pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
         };
         auto store_patch = [&](int buf) {
+            if constexpr ((SP_ABLATE & 4) != 0) return;
             char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
             char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
 #pragma unroll
@@ -167,6 +176,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
         };
         // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
         auto issue_A = [&](int grp, int tgi, int abuf) {
+            if constexpr ((SP_ABLATE & 1) != 0) return;
             const int tb = tgi * TG;
             int nt = T - tb;
             nt = nt < TG ? nt : TG;
@@ -267,6 +277,11 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                     }
                 };
                 auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+                    if constexpr ((SP_ABLATE & 8) != 0) {
+                        acc[0][0][0] += (float)a[0][0][0] + (float)a[0][1][0] + (float)a[MI - 1][0][0] + (float)a[MI - 1][1][0] + (float)b[0][0][0] +
+                                        (float)b[0][1][0] + (float)b[NI - 1][0][0] + (float)b[NI - 1][1][0];
+                        return;
+                    }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) {
                             const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
-                            if (m < g.M) {
+                            if (m < g.M && ((SP_ABLATE & 16) == 0 || acc[mi][ni][rr] == 123.456f)) {
                                 if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
                                 else yo[(long)m * ohw] = acc[mi][ni][rr];
                             }
