@@ -20,11 +20,43 @@
 #include "igemm_geom.h"
 #include "pack_bodies.h"
 #include <cstdlib>
+#include <cstdint>
+#include <type_traits>
+
+#ifndef SP_WIDE
+#define SP_WIDE 1                 // 0: one dword store per accumulator register (round 1/2)
+#endif
+#ifndef SP_PROD_FIRST
+#define SP_PROD_FIRST 0           // 1: waves 0-3 produce (the older wave of a SIMD wins issue arbitration), 4-7 consume
+#endif
+#ifndef SP_PRIO
+#define SP_PRIO 0                 // s_setprio of the producer waves
+#endif
+#ifndef SP_STAGGER
+#define SP_STAGGER 0              // (experiment) start phase step of the persistent blocks, in units of 64 cycles (s_sleep), x (block & 7)
+#endif
+#ifndef SP_TRACE
+#define SP_TRACE 0                // diagnostics (tools/variants.py + tools/sp_trace.py): block 0 stamps s_memtime of its phases, slabs 16 .. 47
+#endif
+#if SP_TRACE
+__device__ unsigned faoctasr_sp_trace_buf[4096];
+extern "C" int faoctasr_sp_trace_read(unsigned* host_out, int n) {
+    if (!host_out || n < 0 || n > 4096) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(faoctasr_sp_trace_buf), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#define SPTRACE(cond, base, q, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (cond) && (q) >= 16 && (q) < 48) faoctasr_sp_trace_buf[(base) + ((q) - 16) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPTRACE(cond, base, q, k) do { } while (0)
+#endif
 
 namespace faoctasr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 #ifndef SP_ABLATE
 #define SP_ABLATE 0               // diagnostics (tools/variants.py): 1 no weight DMA, 2 no patch loads, 4 no split / patch stores, 8 no MFMA, 16 no output stores
@@ -39,6 +71,27 @@ __device__ __forceinline__ int reflect_idx_s(int i, int n) {
 }
 
 __device__ __forceinline__ void ds_read_v8(bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); }
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_sp(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_sp<I + 1, N>(f);
+    }
+}
+
+// every LDS read retired; naming the registers keeps the consumer MFMAs below the wait
+template <int MI, int NI>
+__device__ __forceinline__ void wait_all(bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
+    if constexpr (MI == 2 && NI == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+    else if constexpr (MI == 2 && NI == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0][0]), "+v"(b[0][1]));
+    else if constexpr (MI == 1 && NI == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1]));
+}
 
 // wait until only the OTHER fragment set's (MI + NI) * 2 reads are still outstanding; naming the registers keeps the consumer
 // MFMAs below the wait
@@ -69,15 +122,18 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // whose pipes overlap.  The two roles run SEPARATE loops over the identical (tile, channel group, tap group) sequence and meet
 // at one s_barrier per slab, so the register allocation is max(producer, consumer), not their sum.  Blocks are persistent over
 // pixel tiles and the pipeline does not drain at tile boundaries.
-template <int NI, int SI>
+// QUAD: the producers stage the patch in 4-pixel pieces (round 3): a thread's item is (channel half, patch row, 4 consecutive pixels
+// starting at a 16-byte aligned image column) = 8 x buffer_load_dwordx4, one per channel, instead of 32 dword loads; the <= 3 + 3
+// columns of a patch row left and right of the aligned run stay single-pixel items.  Host-side conditions: sp_quad_ok().
+template <int NI, int SI, bool QUAD>
 __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
-                                                           const int ksplit) {
+                                                           const int ksplit, const int wide) {
     constexpr int MI = 2, TH = 4 * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const bool producer = wave >= 4;
+    const bool producer = SP_PROD_FIRST ? wave < 4 : wave >= 4;
     const int wn = wave & 3, stid = tid & 255;
     const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
@@ -85,6 +141,11 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
     const int tiles = tiles_x * tiles_y;
     const long total_tiles = (long)g.N * tiles;
     if ((long)blockIdx.x >= total_tiles) return;
+#if SP_STAGGER
+    // The persistent blocks do identical work per slab and would run in step: every CU asking the fabric for its next patch in the
+    // same microsecond, then none for the rest of the slab.  Start them at eight different phases of a slab instead.
+    for (int i = (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 7); i > 0; --i) __builtin_amdgcn_s_sleep(SP_STAGGER);
+#endif
     const int t0 = g.t0[ph], T = g.t0[ph + 1] - t0, TG = g.tg[ph];
     const int ntg = (T + TG - 1) / TG;
     const int PH = (TH - 1) * SI + g.span_y[ph] + 1, PW = 31 * SI + g.span_x[ph] + 1, PHW = PH * PW;
@@ -98,69 +159,174 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
     const long chw = (long)IH * IW;
     const unsigned a_bytes = (unsigned)TG * 2048u;                      // per plane per buffer: TG taps x 2 halves x 64 rows x 16 B
     const unsigned p_bytes = (unsigned)(2 * PHW) * 16u;                 // per plane per buffer
-    const unsigned A_base = 0, P_base = 4u * a_bytes;
-    auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {
-        n = (int)(tl / tiles);
-        const int rt = (int)(tl - (long)n * tiles);
-        ty = rt / tiles_x;
+    const unsigned A_base = 0, P_base = 4u * a_bytes, S_base = P_base + 4u * p_bytes;       // S: 4 x 4 KiB of output staging
+    auto tile_coords = [&](long tl, int& n, int& ty, int& tx) {       // total_tiles < 2^31 (sp_launch): 32-bit divisions
+        n = (int)((unsigned)tl / (unsigned)tiles);
+        const int rt = (int)((unsigned)tl - (unsigned)n * (unsigned)tiles);
+        ty = (int)((unsigned)rt / (unsigned)tiles_x);
         tx = rt - ty * tiles_x;
     };
 
     if (producer) {
         // ================================================ PRODUCER ================================================
+        if constexpr (SP_PRIO != 0) __builtin_amdgcn_s_setprio(SP_PRIO);
         constexpr unsigned OOB = 0x80000000u;
-        unsigned poff[NPI];
-        const int nitems = 2 * PHW;
-        const float invPW = 1.0f / (float)PW;
         const unsigned cstep = 4u * (unsigned)chw;
         const float* xin = x;
-        float pv[NPI][8];
-        if constexpr ((SP_ABLATE & 2) != 0)
-            for (int i = 0; i < NPI; ++i)
+        // ---- single-pixel items (all of the patch when !QUAD)
+        constexpr int NSI = QUAD ? 2 : NPI;
+        unsigned poff[NSI];
+        float pv[NSI][8];
+        // ---- 4-pixel items
+        constexpr int NQI = QUAD ? 2 : 1;
+        unsigned qoff[NQI];
+        f32x4s qv[NQI][8];
+        // Patch columns qs .. qs + 4 nq - 1 are 4-pixel pieces; qs is the first column whose image column is a multiple of 4 (tile
+        // origins are), or -- zero padding -- the piece before it, so that the pieces cover the whole row and the columns they
+        // have beyond it are simply not stored (a piece beyond the image row reads zeros: its offset is the out-of-range
+        // sentinel).  A producer wave's memory instructions issue at 160-300 cycles apiece beside its SIMD's MFMA stream
+        // (s_memtime trace), so what counts is their NUMBER: 3x3, 16 channels: 8 per wave instead of 48.
+        const int qx0 = (-g.ox0[ph]) & 3;
+        const bool cover = QUAD && !g.reflect;
+        const int qs = cover && qx0 ? qx0 - 4 : qx0;
+        const int nq = QUAD ? (cover ? (PW - qs + 3) >> 2 : (PW - qx0) >> 2) : 0;
+        const int ns = cover ? 0 : PW - 4 * nq;                          // single columns per patch row: qx0 on the left, the rest on the right
+        const int nqi = 2 * PH * nq, nitems = 2 * PH * ns;
+        // item -> (h, patch row, patch column): fixed for the kernel; only the image offsets change with the tile
+        int s_pos[NSI], q_pos[NQI];                                      // py | (px + 4) << 8 | h << 16, or -1
+        int s_slot[NSI], q_slot[NQI];                                    // LDS slot (16-byte units) of the item's first pixel (a covering piece: may lie before its row)
+        {
+            const float inv_ns = 1.0f / (float)(ns > 0 ? ns : 1), inv_nq = 1.0f / (float)(nq > 0 ? nq : 1);
+#pragma unroll
+            for (int i = 0; i < NSI; ++i) {
+                const int it = stid + NT * i;
+                s_pos[i] = -1;
+                s_slot[i] = 0;
+                if (it < nitems) {
+                    const int h = it >= PH * ns ? 1 : 0;
+                    const int r = it - h * PH * ns;
+                    const int py = (int)(((float)r + 0.5f) * inv_ns);
+                    const int sx = r - py * ns;
+                    const int px = sx < qx0 ? sx : sx + 4 * nq;
+                    s_pos[i] = py | ((px + 4) << 8) | (h << 16);
+                    s_slot[i] = h * PHW + py * PW + px;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NQI; ++i) {
+                const int it = stid + NT * i;
+                q_pos[i] = -1;
+                q_slot[i] = 0;
+                if (QUAD && it < nqi) {
+                    const int h = it >= PH * nq ? 1 : 0;
+                    const int r = it - h * PH * nq;
+                    const int py = (int)(((float)r + 0.5f) * inv_nq);
+                    const int px = qs + 4 * (r - py * nq);
+                    q_pos[i] = py | ((px + 4) << 8) | (h << 16);
+                    q_slot[i] = h * PHW + py * PW + px;
+                }
+            }
+        }
+        if constexpr ((SP_ABLATE & 2) != 0) {
+            for (int i = 0; i < NSI; ++i)
                 for (int j = 0; j < 8; ++j) pv[i][j] = (float)(tid + i + j);
+            for (int i = 0; i < NQI; ++i)
+                for (int j = 0; j < 8; ++j) qv[i][j] = f32x4s{(float)tid, (float)i, (float)j, 1.f};
+        }
         auto compute_poff = [&](long tl) {
             int n, ty, tx;
             tile_coords(tl, n, ty, tx);
             const int y_base = ty * TH * SI + g.oy0[ph], x_base = tx * 32 * SI + g.ox0[ph];
             xin = x + (long)n * g.C * chw;
-#pragma unroll
-            for (int i = 0; i < NPI; ++i) {
-                const int it = stid + NT * i;                           // item = h*PHW + pixel
-                unsigned off = OOB;
-                if (it < nitems) {
-                    const int h = it >= PHW ? 1 : 0;
-                    const int p = it - h * PHW;
-                    const int py = (int)(((float)p + 0.5f) * invPW);
-                    const int px = p - py * PW;
-                    int iy = y_base + py, ix = x_base + px;
-                    if (g.reflect) {
-                        iy = reflect_idx_s(iy, IH);
-                        ix = reflect_idx_s(ix, IW);
-                    }
-                    if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) off = 4u * (unsigned)(8 * h * (int)chw + iy * IW + ix);
+            auto off_of = [&](int pos) -> unsigned {
+                if (pos < 0) return OOB;
+                int iy = y_base + (pos & 0xff), ix = x_base + ((pos >> 8) & 0xff) - 4;
+                if (g.reflect) {
+                    iy = reflect_idx_s(iy, IH);
+                    ix = reflect_idx_s(ix, IW);                          // 4-pixel items: inside the row by sp_quad_ok, so this leaves them alone
                 }
-                poff[i] = off;
-            }
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) return 4u * (unsigned)(8 * (pos >> 16) * (int)chw + iy * IW + ix);
+                return OOB;
+            };
+#pragma unroll
+            for (int i = 0; i < NSI; ++i) poff[i] = off_of(s_pos[i]);
+#pragma unroll
+            for (int i = 0; i < NQI; ++i) qoff[i] = off_of(q_pos[i]);
         };
         auto load_patch = [&](int grp) {
             if constexpr ((SP_ABLATE & 2) != 0) return;
             const long bytes = (long)(g.C - grp * 16) * chw * 4;
             const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (long)grp * 16 * chw), 0,
                                                                (int)(bytes < 0x7ffffff0L ? bytes : 0x7ffffff0L), 0x00020000);
+            if constexpr (QUAD) {
 #pragma unroll
-            for (int i = 0; i < NPI; ++i)
+                for (int i = 0; i < NQI; ++i)
+                    if (NT * i < nqi) {                                  // block-uniform: no instruction for an item row nobody has
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
+                        for (int j = 0; j < 8; ++j)
+                            qv[i][j] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(srd, qoff[i] + j * cstep, 0, 0));
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < NSI; ++i)
+                if (NT * i < nitems) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        pv[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd, poff[i] + j * cstep, 0, 0));
+                }
         };
-        auto store_patch = [&](int buf) {
+        auto store_patch = [&](int buf, auto&& hook) {                   // hook(): one weight DMA, if any is left (see the loop below)
             if constexpr ((SP_ABLATE & 4) != 0) return;
             char* hi_p = smem + P_base + (buf * 2 + 0) * p_bytes;
             char* lo_p = smem + P_base + (buf * 2 + 1) * p_bytes;
+            if constexpr (QUAD) {
 #pragma unroll
-            for (int i = 0; i < NPI; ++i) {
-                const int it = stid + NT * i;
-                if (it < nitems) {
+                for (int i = 0; i < NQI; ++i) {
+                    if (NT * i < nqi) {                                  // block-uniform (hook() issues a DMA: every lane must be there);
+                        const bool qok = q_pos[i] >= 0;                  // lanes without an item compute on zeros and store nothing
+                        const int px0 = ((q_pos[i] >> 8) & 0xff) - 4;
+                        // hi = bf16(x) of two CHANNELS of a pixel is one v_cvt_pk_bf16_f32 (the LDS order); x - float(hi) of two PIXELS
+                        // of a channel is one v_pk_add_f32 on the register pair the dwordx4 load left them in: 2.5 instructions per
+                        // element and no moves (pairing channels for the subtraction cost two v_mov per pair)
+                        unsigned hd[4][4], ld[4][4];                     // [pixel][channel pair]
+                        f32x2s lo[8][2];                                 // [channel][pixel pair]
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int c2 = 0; c2 < 4; ++c2)
+                                hd[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{qv[i][2 * c2][k], qv[i][2 * c2 + 1][k]}, bf16x2s));
+                        hook();
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                            for (int kp = 0; kp < 2; ++kp) {
+                                const unsigned d0 = hd[2 * kp][c >> 1], d1 = hd[2 * kp + 1][c >> 1];
+                                const f32x2s hf = {__builtin_bit_cast(float, (c & 1) ? d0 & 0xffff0000u : d0 << 16),
+                                                   __builtin_bit_cast(float, (c & 1) ? d1 & 0xffff0000u : d1 << 16)};
+                                lo[c][kp] = f32x2s{qv[i][c][2 * kp], qv[i][c][2 * kp + 1]} - hf;
+                            }
+                            if (c & 1) hook();
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int c2 = 0; c2 < 4; ++c2)
+                                ld[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{lo[2 * c2][k >> 1][k & 1], lo[2 * c2 + 1][k >> 1][k & 1]}, bf16x2s));
+                        hook();
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (qok && (unsigned)(px0 + k) < (unsigned)PW) {        // not: a covering piece's columns beyond the patch row
+                                *reinterpret_cast<u32x4s*>(hi_p + (q_slot[i] + k) * 16) = u32x4s{hd[k][0], hd[k][1], hd[k][2], hd[k][3]};
+                                *reinterpret_cast<u32x4s*>(lo_p + (q_slot[i] + k) * 16) = u32x4s{ld[k][0], ld[k][1], ld[k][2], ld[k][3]};
+                            }
+                            hook();
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NSI; ++i) {
+                if (s_pos[i] >= 0) {
                     bf16x8 hv, lv;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -169,35 +335,98 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                         hv[j] = hb;
                         lv[j] = (__bf16)(v - (float)hb);
                     }
-                    *reinterpret_cast<bf16x8*>(hi_p + it * 16) = hv;
-                    *reinterpret_cast<bf16x8*>(lo_p + it * 16) = lv;
+                    *reinterpret_cast<bf16x8*>(hi_p + s_slot[i] * 16) = hv;
+                    *reinterpret_cast<bf16x8*>(lo_p + s_slot[i] * 16) = lv;
                 }
             }
         };
-        // A slab (group grp, tap group tgi) -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB
-        auto issue_A = [&](int grp, int tgi, int abuf) {
-            if constexpr ((SP_ABLATE & 1) != 0) return;
+        // A slab (group grp, tap group tgi) of packed weights -> LDS buffer abuf: per plane ntaps*2 rows of 1 KiB that LDS-DMA copies
+        // verbatim.  Everything but the lane's 16 bytes inside the row is wave-uniform and kept on the scalar unit (with `wn` in a
+        // vector register the compiler ran this loop under an exec mask with ~28 vector instructions per DMA).
+        const int wnu = __builtin_amdgcn_readfirstlane(wn);
+        const char* const wbase = reinterpret_cast<const char*>(wp + g.pack_off[ph] + (long)m0 * 8);
+        const long w_row = (long)g.Mpad * 16, w_plane = g.plane_stride * 2;      // bytes between rows / planes
+        const unsigned lane16 = (unsigned)lane * 16u;
+        // One DMA at a time: the rows of the slab being fetched are handed out by next_row(); the split of the patch (vector ALU work)
+        // calls it between its steps.  Memory instructions of this CU are accepted at ~25 B/clk whoever issues them (s_memtime:
+        // 9 DMA + 8 loads of 1 KiB per wave took 2700 cycles with the MFMA waves parked at a barrier, 3400 beside them): issued in
+        // a bunch a wave just sits in front of a full queue; with ~12 vector instructions between two of them the queue has
+        // drained when the next one arrives.
+        const char* d_src = wbase;                                       // row cursor of the slab being fetched
+        char* d_dst = smem;
+        int d_r = 0, d_rows = 0, d_rows2 = 0;
+        auto begin_A = [&](int grp, int tgi, int abuf) {
             const int tb = tgi * TG;
             int nt = T - tb;
             nt = nt < TG ? nt : TG;
-            const int rows = nt * 2;                                    // (tap, h)
-            for (int r = wn; r < 2 * rows; r += 4) {
-                const int plane = r >= rows ? 1 : 0;
-                const int rr = r - plane * rows;                        // tl*2 + h
-                const __bf16* src = wp + plane * g.plane_stride + g.pack_off[ph] +
-                                    ((((long)grp * T + tb) * 2 + rr) * g.Mpad + m0) * 8 + lane * 8;
-                char* dst = smem + A_base + (abuf * 2 + plane) * a_bytes + rr * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            d_rows = nt * 2;                                            // (tap, h) rows per plane
+            d_rows2 = (SP_ABLATE & 1) ? 0 : 2 * d_rows;
+            d_r = wnu;
+            d_src = wbase + ((long)grp * T + tb) * 2 * w_row;
+            d_dst = smem + A_base + (abuf * 2) * a_bytes;
+        };
+        auto next_row = [&]() {
+            if (d_r < d_rows2) {
+                const int plane = d_r >= d_rows ? 1 : 0;
+                const int rr = d_r - plane * d_rows;                    // tl*2 + h
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(d_src + plane * w_plane + rr * w_row + lane16),
+                                                 (__attribute__((address_space(3))) void*)(d_dst + plane * a_bytes + rr * 1024), 16, 0, 0);
+                d_r += 4;
             }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto rest_of_A = [&]() {
+            while (d_r < d_rows2) next_row();
         };
 
+        // Patch pipeline, two patches deep (round 3).  Patch p = (tile, channel group) in the order the consumers walk them.  While the
+        // consumers reduce patch p from LDS, patch p + 1 waits in registers and is split + stored at the LAST slab of p, and the loads
+        // of patch p + 2 are issued right behind that store -- a whole slab before their use (round 1 issued them at the start of the
+        // slab that stores them).  The weight DMA of the next slab is issued BEFORE the patch loads, so that `vmcnt(number of patch
+        // loads)` -- loads return in order -- says "the DMA has landed" at the barrier without waiting for the patch.
+        long tile_l = blockIdx.x;                                        // load cursor
+        int grp_l = g0;
+        bool valid_l = true;
+        auto advance_l = [&]() {
+            if (++grp_l >= g1) {
+                grp_l = g0;
+                tile_l += gridDim.x;
+                valid_l = tile_l < total_tiles;
+                if (valid_l) compute_poff(tile_l);
+            }
+        };
+        int npl_full = 0;                                                // memory instructions of one load_patch (block-uniform)
+        if constexpr ((SP_ABLATE & 2) == 0) {
+            for (int i = 0; i < NQI; ++i) npl_full += (QUAD && NT * i < nqi) ? 8 : 0;
+            for (int i = 0; i < NSI; ++i) npl_full += NT * i < nitems ? 8 : 0;
+        }
+        auto barrier_keep = [&](int n) {                                 // LDS stores visible, everything but the last n memory loads landed
+            switch (n) {
+                case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 24: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 32: asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 40: asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case 48: asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            }
+        };
+        auto no_hook = [&]() {};
+
+        compute_poff(tile_l);
+        load_patch(grp_l);                                               // patch 0
+        advance_l();
+        begin_A(g0, 0, 0);
+        rest_of_A();
+        store_patch(0, no_hook);
+        int in_flight = 0;
+        if (valid_l) {
+            load_patch(grp_l);                                           // patch 1
+            advance_l();
+        }
+        barrier_keep(0);
         long tile = blockIdx.x;
-        compute_poff(tile);
-        load_patch(g0);
-        issue_A(g0, 0, 0);
-        store_patch(0);
-        __syncthreads();
         int slab = 0, pcount = 0;
         while (true) {
             const long next_tile = tile + gridDim.x;
@@ -205,21 +434,28 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
             for (int grp = g0; grp < g1; ++grp, ++pcount) {
                 const int pbuf = pcount & 1;
                 const bool last_grp = grp + 1 >= g1;
-                // prefetch the next patch (next channel group, or the first group of the NEXT tile) into registers
-                if (!last_grp) {
-                    load_patch(grp + 1);
-                } else if (has_next) {
-                    compute_poff(next_tile);
-                    load_patch(g0);
-                }
                 const bool more_patch = !last_grp || has_next;
                 for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
                     const int abuf = slab & 1;
-                    if (tgi + 1 < ntg) issue_A(grp, tgi + 1, abuf ^ 1);
-                    else if (!last_grp) issue_A(grp + 1, 0, abuf ^ 1);
-                    else if (has_next) issue_A(g0, 0, abuf ^ 1);
-                    if (tgi == ntg - 1 && more_patch) store_patch(pbuf ^ 1);
-                    __syncthreads();                                     // LDS-DMA landed (vmcnt(0)), patch visible, consumers done
+                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 3072, slab, 0);
+                    in_flight = 0;
+                    const bool swap_patch = tgi == ntg - 1 && more_patch;
+                    d_rows2 = 0;
+                    if (tgi + 1 < ntg) begin_A(grp, tgi + 1, abuf ^ 1);
+                    else if (!last_grp) begin_A(grp + 1, 0, abuf ^ 1);
+                    else if (has_next) begin_A(g0, 0, abuf ^ 1);
+                    if (swap_patch) store_patch(pbuf ^ 1, next_row);     // patch p + 1 (loaded a slab or a channel group ago), DMA in between
+                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 0);
+                    rest_of_A();
+                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 1);
+                    if (swap_patch && valid_l) {
+                        load_patch(grp_l);                               // patch p + 2
+                        advance_l();
+                        in_flight = npl_full;
+                    }
+                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 2);
+                    barrier_keep(in_flight);                             // LDS-DMA landed, patch visible, consumers done
+                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 3);
                 }
             }
             if (!has_next) break;
@@ -247,7 +483,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
     const unsigned b_row = (unsigned)(SI * PW) * 16u;
 
     long tile = blockIdx.x;
-    __syncthreads();                                                    // first patch + first weight slab staged by the producers
+    asm volatile("s_barrier" ::: "memory");                             // first patch + first weight slab staged by the producers
     int slab = 0, pcount = 0;
     while (true) {
         const long next_tile = tile + gridDim.x;
@@ -262,7 +498,11 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                 const unsigned Ah = lds0 + A_base + (abuf * 2 + 0) * a_bytes + a_lane, Al = Ah + a_bytes;
                 const unsigned Ph = lds0 + P_base + (pbuf * 2 + 0) * p_bytes + b_lane, Pl = Ph + p_bytes;
                 bf16x8 a0[MI][2], b0[NI][2], a1[MI][2], b1[NI][2];
-                auto rd = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], int tl) {
+                // One tap step = 3 MI NI MFMAs on the CURRENT fragment set with the 2 (MI + NI) ds_read_b128 of the NEXT tap's set
+                // issued one per MFMA gap (round 3; the round-1 loop issued the eight reads in a bunch before the twelve MFMAs and
+                // the matrix pipe idled for ~170 of every 560 cycles: s_memtime trace).  Terms outermost, so that
+                // consecutive MFMAs go to different accumulators.
+                auto rd_all = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], int tl) {
                     const unsigned ao = (unsigned)tl * 2048u;
                     const unsigned bo = 16u * (unsigned)__builtin_amdgcn_readlane(tapv, (tb + tl) & 63);
 #pragma unroll
@@ -276,36 +516,37 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                         ds_read_v8(b[ni][1], Pl + bo + ni * b_row);
                     }
                 };
-                auto mm = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2]) {
-                    if constexpr ((SP_ABLATE & 8) != 0) {
-                        acc[0][0][0] += (float)a[0][0][0] + (float)a[0][1][0] + (float)a[MI - 1][0][0] + (float)a[MI - 1][1][0] + (float)b[0][0][0] +
-                                        (float)b[0][1][0] + (float)b[NI - 1][0][0] + (float)b[NI - 1][1][0];
-                        return;
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], acc[mi][ni], 0, 0, 0);   // lo*hi
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], acc[mi][ni], 0, 0, 0);   // hi*lo
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], acc[mi][ni], 0, 0, 0);   // hi*hi
+                auto step = [&](bf16x8 (&a)[MI][2], bf16x8 (&b)[NI][2], bf16x8 (&an)[MI][2], bf16x8 (&bn)[NI][2], int tl_next) {
+                    const unsigned ao = (unsigned)tl_next * 2048u;       // past the slab on its last step: read, never used
+                    const unsigned bo = 16u * (unsigned)__builtin_amdgcn_readlane(tapv, (tb + tl_next) & 63);
+                    wait_all<MI, NI>(a, b);
+                    static_for_sp<0, 3 * MI * NI>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        constexpr int term = j / (MI * NI), t = j % (MI * NI), mi = t / NI, ni = t % NI;
+                        if constexpr ((SP_ABLATE & 8) != 0) {
+                            if constexpr (j == 0) acc[0][0][0] += (float)a[0][0][0] + (float)a[MI - 1][1][0] + (float)b[0][0][0] + (float)b[NI - 1][1][0];
+                        } else {
+                            // term 0: lo*hi, 1: hi*lo, 2: hi*hi
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][term == 0 ? 1 : 0], b[ni][term == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
                         }
+                        if constexpr (j < 2 * MI) ds_read_v8(an[j / 2][j % 2], (j % 2 ? Al : Ah) + ao + (j / 2) * 512u);
+                        else if constexpr (j < 2 * (MI + NI)) ds_read_v8(bn[(j - 2 * MI) / 2][(j - 2 * MI) % 2], ((j - 2 * MI) % 2 ? Pl : Ph) + bo + ((j - 2 * MI) / 2) * b_row);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 };
+                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
-                rd(a0, b0, 0);
+                rd_all(a0, b0, 0);
                 for (int tl = 0; tl < nt; tl += 2) {
-                    rd(a1, b1, tl + 1);                                 // runs past the slab on the last odd step: never used
-                    wait_keep_next<MI, NI>(a0, b0);
-                    mm(a0, b0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    step(a0, b0, a1, b1, tl + 1);
                     if (tl + 1 >= nt) break;
-                    rd(a0, b0, tl + 2);
-                    wait_keep_next<MI, NI>(a1, b1);
-                    mm(a1, b1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    step(a1, b1, a0, b0, tl + 2);
                 }
+                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // retire run-ahead reads before LDS is rewritten
-                __syncthreads();
+                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 2);
+                asm volatile("s_barrier" ::: "memory");                  // no vmcnt wait: the tile's output stores drain behind the next tile's MFMAs
+                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 3);
             }
         }
         // ---- epilogue of this tile; the producers are already staging the next tile
@@ -347,21 +588,53 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = tanhf(acc[mi][ni][rr]);
             }
-            const long ohw = (long)g.OH * g.OW;
+            // one image's M x OH x OW outputs are < 2^30 (sp_launch): a uniform image pointer + 32-bit lane offsets, one
+            // multiply-add per element (round 1: a 64-bit address and a bounds branch per element, ~5700 cycles per tile)
+            const unsigned ohw = (unsigned)(g.OH * g.OW);
             const int bo = ctx * 32 + l31;
+            float* const yimg = y + (long)cn * g.M * (long)ohw;
+            const bool full_m = m0 + SP_MT <= g.M;
+            if (wide) {
+                // 32 x 32 accumulator tile -> the wave's 4 KiB of staging (a lane holds ONE pixel of 16 rows) -> a lane reads 4
+                // pixels of a row back: 4 dwordx4 stores per tile, each 8 rows x 128 B, instead of 16 dword stores of 2 x 128 B.
+                // The stores of a wave drain at its memory-instruction rate (s_memtime trace: 64 of them = the 8100-cycle tile
+                // boundary); LDS accesses of one wave execute in order, the region is the wave's own: no barrier.
+                float* const S = reinterpret_cast<float*>(smem + S_base) + wn * 1024;
+                const int prow = lane >> 3, pq = lane & 7;
+                const int ox = ctx * 32 + 4 * pq;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ao = cty * TH + wn * NI + ni;
+                    const bool ok = ao < GH && ox < GW;
+                    const unsigned o0 = (unsigned)(m0 + prow) * ohw + (unsigned)((ao + g.py[ph]) * g.OW + ox + g.px[ph]);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) S[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * 32 + l31] = acc[mi][ni][rr];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4s v = *reinterpret_cast<const f32x4s*>(S + (prow + 8 * i) * 32 + 4 * pq);
+                            const int dm = mi * 32 + 8 * i;
+                            if (ok && (full_m || m0 + prow + dm < g.M) && ((SP_ABLATE & 16) == 0 || v[0] == 123.456f))
+                                *reinterpret_cast<f32x4s*>(yimg + (o0 + (unsigned)dm * ohw)) = v;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int ao = cty * TH + wn * NI + ni;
                 if (ao < GH && bo < GW) {
-                    float* yo = y + (long)cn * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
+                    const unsigned o0 = (unsigned)mrow0 * ohw + (unsigned)((ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]));
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) {
-                            const int m = mrow0 + mi * 32 + (rr & 3) + 8 * (rr >> 2);
-                            if (m < g.M && ((SP_ABLATE & 16) == 0 || acc[mi][ni][rr] == 123.456f)) {
-                                if (ksplit > 1) atomicAdd(yo + (long)m * ohw, acc[mi][ni][rr]);
-                                else yo[(long)m * ohw] = acc[mi][ni][rr];
+                            const int dm = mi * 32 + (rr & 3) + 8 * (rr >> 2);
+                            if ((full_m || mrow0 + dm < g.M) && ((SP_ABLATE & 16) == 0 || acc[mi][ni][rr] == 123.456f)) {
+                                float* const p = yimg + (o0 + (unsigned)dm * ohw);
+                                if (ksplit > 1) atomicAdd(p, acc[mi][ni][rr]);
+                                else *p = acc[mi][ni][rr];
                             }
                         }
                     }
@@ -384,12 +657,12 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t SP_LDS_MAX = 156 * 1024;
 
-static size_t sp_lds(const SplitGeom& g, int NI, int SI) {
+static size_t sp_lds(const SplitGeom& g, int NI, int SI, bool staging = true) {
     const int TH = 4 * NI;
     size_t best = 0;
     for (int p = 0; p < g.nphase; ++p) {
         const int PH = (TH - 1) * SI + g.span_y[p] + 1, PW = 31 * SI + g.span_x[p] + 1;
-        const size_t b = 4 * (size_t)g.tg[p] * 2048 + 4 * (size_t)(2 * PH * PW) * 16 + 2048;
+        const size_t b = 4 * (size_t)g.tg[p] * 2048 + 4 * (size_t)(2 * PH * PW) * 16 + (staging ? 16384 : 0) + 2048;      // weights, patch, output staging
         best = b > best ? b : best;
     }
     return best;
@@ -401,7 +674,7 @@ static bool sp_fits(const SplitGeom& g, int NI, int SI) {
         const int PH = (TH - 1) * SI + g.span_y[p] + 1, PW = 31 * SI + g.span_x[p] + 1;
         if (2 * PH * PW > 256 * SP_NPI) return false;
     }
-    return sp_lds(g, NI, SI) <= SP_LDS_MAX;
+    return sp_lds(g, NI, SI, false) <= SP_LDS_MAX;                     // the output staging is optional (sp_launch)
 }
 
 // 1 when the layer can run on the split kernel (decided by the layer shape only)
@@ -446,6 +719,30 @@ int split_geom_from(const IgemmGeom& f, SplitGeom& g) {
     return 1;
 }
 
+// 4-pixel patch items (kernel template QUAD): the image rows and the activation pointer are 16-byte aligned, so a piece that starts
+// at a multiple-of-4 column lies wholly inside its row or wholly outside it; with reflection padding every piece of every tile must
+// lie inside (a mirrored piece would need its pixels one by one); the item counts fit two rounds of the 256 producer threads.
+#ifndef SP_QUAD
+#define SP_QUAD 1                 // 0: single-pixel items only (round 1/2)
+#endif
+static bool sp_quad_ok(const SplitGeom& g, int NI, const float* x) {
+    if (!SP_QUAD || (g.IW & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return false;
+    const int TH = 4 * NI;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int PH = (TH - 1) * g.SI + g.span_y[p] + 1, PW = 31 * g.SI + g.span_x[p] + 1;
+        const int qx0 = (-g.ox0[p]) & 3;
+        const bool cover = !g.reflect;
+        const int qs = cover && qx0 ? qx0 - 4 : qx0;
+        const int nq = cover ? (PW - qs + 3) >> 2 : (PW - qx0) >> 2, ns = cover ? 0 : PW - 4 * nq;
+        if (nq < 1 || 2 * PH * nq > 512 || 2 * PH * ns > 512 || PH > 255 || PW > 240) return false;
+        if (g.reflect) {
+            const int tiles_x = (g.gw[p] + 31) / 32;
+            if (g.ox0[p] + qx0 < 0 || (tiles_x - 1) * 32 * g.SI + g.ox0[p] + qx0 + 4 * nq > g.IW) return false;
+        }
+    }
+    return true;
+}
+
 long split_pack_floats(const SplitGeom& g) { return g.plane_stride + 512; }   // 2 planes x 2 B = 4 B per element, + tail pad
 
 int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t s) {
@@ -464,6 +761,7 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
         mx = t > mx ? t : mx;
     }
     if (mx == 0) return FAOCTASR_OK;
+    if (mx >= (1L << 31) || (long)g.M * g.OH * g.OW >= (1L << 30)) return fail(FAOCTASR_EINVAL, "igemm_bf16x3: tensor too large");
     const int gy = (g.M + SP_MT - 1) / SP_MT;
     const long blocks = mx * gy * g.nphase;
     int ksplit = 1;
@@ -476,20 +774,28 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     if (g_no_split_k) ksplit = 1;
     if (ksplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.N * g.M * g.OH * g.OW, s) != hipSuccess)
         return fail(FAOCTASR_EHIP, "memset y failed");
-    const size_t lds = sp_lds(g, NI, g.SI);
+    const bool staging = sp_lds(g, NI, g.SI, true) <= SP_LDS_MAX;
+    const size_t lds = sp_lds(g, NI, g.SI, staging);
     // persistent blocks: one block per CU walks tiles bx, bx + gridDim.x, ... (the pipeline continues across tile boundaries)
     long nbx = 256 / ((long)gy * g.nphase * ksplit);
     nbx = nbx < 1 ? 1 : nbx;
     if (nbx > mx) nbx = mx;
     dim3 grid((unsigned)nbx, gy, g.nphase * ksplit);
+    const bool quad = sp_quad_ok(g, NI, x);
+    // 16-byte output pieces: unit output stride, rows and the tensor 16-byte aligned, whole pieces inside the grid, no atomics
+    bool wide_ok = SP_WIDE && staging && g.SO == 1 && g.nphase == 1 && (g.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && ksplit == 1;
+    for (int p = 0; p < g.nphase; ++p) wide_ok = wide_ok && (g.gw[p] & 3) == 0 && (g.px[p] & 3) == 0;
+    const int wide = wide_ok ? 1 : 0;
+    auto go = [&](auto k) {
+        lds_optin((const void*)k, lds);
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit, wide);
+    };
     if (g.SI == 1) {
-        auto k = igemm_bf16x3_kernel<NI, 1>;
-        lds_optin((const void*)k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        if (quad) go(igemm_bf16x3_kernel<NI, 1, true>);
+        else go(igemm_bf16x3_kernel<NI, 1, false>);
     } else {
-        auto k = igemm_bf16x3_kernel<NI, 2>;
-        lds_optin((const void*)k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit);
+        if (quad) go(igemm_bf16x3_kernel<NI, 2, true>);
+        else go(igemm_bf16x3_kernel<NI, 2, false>);
     }
     return check_launch("igemm_bf16x3");
 }

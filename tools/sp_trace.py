@@ -1,0 +1,26 @@
+"""s_memtime phase trace of igemm_bf16x3_kernel, block 0 (an SP_TRACE=1 build: tools/variants.py igemm_bf16x3.hip SP_TRACE 1;
+run with FAOCTASR_LIB=tools/variants/libfaoctasr_SP_TRACE_1.so).  usage: python tools/sp_trace.py [C M H]"""
+import sys, ctypes
+import numpy as np
+import torch
+sys.path.insert(0, "/root/repo")
+import faoctasr
+from faoctasr import ops
+lib = faoctasr._lib.load()
+ops.conv_precision = ops.PRECISIONS["bf16x3"]
+C, M, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (64, 64, 256)))
+x = torch.randn(8, C, H, H, device="cuda"); w = torch.randn(M, C, 3, 3, device="cuda") * 0.05
+with torch.no_grad():
+    for _ in range(2):
+        y = ops.conv2d(x, w, None, 1, 1, False, None, 0.2)
+torch.cuda.synchronize()
+raw = (ctypes.c_uint * 4096)()
+assert lib.faoctasr_sp_trace_read(raw, 4096) == 0, "not an SP_TRACE=1 build"
+t = np.frombuffer(raw, dtype=np.uint32).astype("int64")
+p = t[1024:1152].reshape(32, 4); c = t[2048:2176].reshape(32, 4); pl = t[3072:3200].reshape(32, 4)
+d = lambda a, b: int((a - b) & 0xffffffff)
+print("slab | producer wave 4: split+stores+DMA  rest of DMA  patch load issue  barrier | consumer wave 0: fragment+MFMA loop  drain  barrier  (to next slab start)")
+for i in range(24):
+    nxt = d(c[i + 1][0], c[i][3])
+    print("%4d | %6d %6d %6d %6d | %6d %6d %6d %6d" % (16 + i, d(p[i][0], pl[i][0]), d(p[i][1], p[i][0]), d(p[i][2], p[i][1]), d(p[i][3], p[i][2]),
+          d(c[i][1], c[i][0]), d(c[i][2], c[i][1]), d(c[i][3], c[i][2]), nxt))
