@@ -64,6 +64,16 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+template <unsigned IMM>
+__device__ __forceinline__ void x3_read_tr(bf16x4& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM)); }
+template <unsigned IMM>
+__device__ __forceinline__ void x3_read_128(bf16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM)); }
+// every LDS read retired; naming the registers keeps the MFMAs that use them below the wait
+__device__ __forceinline__ void x3_wait_set(bf16x8& ah, bf16x8& al, bf16x4 (&bh)[3][2], bf16x4 (&bl)[3][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[2][0]), "+v"(bh[2][1]),
+                 "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[2][0]), "+v"(bl[2][1]));
+}
+
 __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                           const WgX3Geom g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,38 +211,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
         __syncthreads();
 
         // ---- contraction: 4 k-blocks of 16 pixels x 9 taps x 3 split products ----
-        x3_static_for<0, 4>([&](auto kc) {
-            constexpr int kb = decltype(kc)::value;
-            constexpr unsigned a_imm = 2u * (unsigned)((kb >> 1) * 32 + 16 * (kb & 1));
-            bf16x8 a_hi, a_lo;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_hi) : "v"(a_addr), "n"(a_imm));
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a_lo) : "v"(a_addr), "n"(a_imm + X3_DPLANE));
-            x3_static_for<0, 3>([&](auto hc) {
-                constexpr int kh = decltype(hc)::value;
-                bf16x4 bh[3][2], bl[3][2];
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
+        // Twelve sub-steps (k-block kb, kernel row kh), each 9 MFMAs on fragment set s & 1 with the 12 transpose reads (+ the two dY
+        // reads of a new k-block) of sub-step s + 1 issued two per MFMA gap into the other set (round 3; before, a sub-step's reads were
+        // issued in a bunch and waited for with lgkmcnt(0) in front of its MFMAs: the LDS latency was exposed twelve times per tile).
+        {
+            bf16x8 a_hi[2], a_lo[2];
+            bf16x4 bh[2][3][2], bl[2][3][2];
+            auto rd = [&](auto sc, auto jc) {                            // read j (0 .. 13) of sub-step s
+                constexpr int s = decltype(sc)::value, j = decltype(jc)::value;
+                constexpr int kb = s / 3, kh = s % 3, set = s & 1;
+                if constexpr (j < 12) {
+                    constexpr int kw = j >> 2, which = j & 3;
                     // pixel of k index j: row (kb >> 1) + kh, column 16 (kb & 1) + j + kw + 3 (patch column 0 = image column x0 - 4, pad 1)
-                    const unsigned imm = (unsigned)(((kb >> 1) + kh) * X3_PCOLS + 16 * (kb & 1) + kw + 3) * 64u;
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[kw][0]) : "v"(b_addr), "n"(imm));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bh[kw][1]) : "v"(b_addr), "n"(imm + 4 * 64));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[kw][0]) : "v"(b_addr), "n"(imm + X3_XPLANE));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bl[kw][1]) : "v"(b_addr), "n"(imm + 4 * 64 + X3_XPLANE));
+                    constexpr unsigned imm = (unsigned)(((kb >> 1) + kh) * X3_PCOLS + 16 * (kb & 1) + kw + 3) * 64u;
+                    if constexpr (which == 0) x3_read_tr<imm>(bh[set][kw][0], b_addr);
+                    else if constexpr (which == 1) x3_read_tr<imm + 4 * 64>(bh[set][kw][1], b_addr);
+                    else if constexpr (which == 2) x3_read_tr<imm + X3_XPLANE>(bl[set][kw][0], b_addr);
+                    else x3_read_tr<imm + 4 * 64 + X3_XPLANE>(bl[set][kw][1], b_addr);
+                } else if constexpr (kh == 0) {                          // a new k-block: its dY fragments
+                    constexpr unsigned a_imm = 2u * (unsigned)((kb >> 1) * 32 + 16 * (kb & 1));
+                    if constexpr (j == 12) x3_read_128<a_imm>(a_hi[kb & 1], a_addr);
+                    else x3_read_128<a_imm + X3_DPLANE>(a_lo[kb & 1], a_addr);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_hi), "+v"(a_lo), "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]), "+v"(bh[2][0]),
-                             "+v"(bh[2][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[2][0]), "+v"(bl[2][1]));
+            };
+            x3_static_for<0, 14>([&](auto jc) { rd(std::integral_constant<int, 0>{}, jc); });
+            x3_static_for<0, 12>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int kb = s / 3, kh = s % 3, set = s & 1, ab = kb & 1;
+                x3_wait_set(a_hi[ab], a_lo[ab], bh[set], bl[set]);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const bf16x8 b_hi = __builtin_shufflevector(bh[kw][0], bh[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8 b_lo = __builtin_shufflevector(bl[kw][0], bl[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                x3_static_for<0, 9>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, kw = m / 3, term = m % 3;
+                    const bf16x8 b_hi = __builtin_shufflevector(bh[set][kw][0], bh[set][kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 b_lo = __builtin_shufflevector(bl[set][kw][0], bl[set][kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     f32x16& d = acc[kh * 3 + kw];
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, d, 0, 0, 0);
-                }
+                    if constexpr (term == 0) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ab], b_hi, d, 0, 0, 0);
+                    else if constexpr (term == 1) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ab], b_lo, d, 0, 0, 0);
+                    else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ab], b_hi, d, 0, 0, 0);
+                    if constexpr (s + 1 < 12 && m < 7) {
+                        rd(std::integral_constant<int, s + 1>{}, std::integral_constant<int, 2 * m>{});
+                        rd(std::integral_constant<int, s + 1>{}, std::integral_constant<int, 2 * m + 1>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             });
-        });
+        }
     }
 
     // ---- epilogue: accumulators [m][channel] per tap -> dW order [m][c][t] through LDS, contiguous atomics ----
