@@ -74,12 +74,19 @@ __device__ __forceinline__ void x3_wait_set(bf16x8& ah, bf16x8& al, bf16x4 (&bh)
                  "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[2][0]), "+v"(bl[2][1]));
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                          const WgX3Geom g) {
+// Wave-specialised (round 3): a 512-thread block, one per CU.  Waves 0-3 contract (wave (mh, cb): 32 rows x 32 channels x 9 taps, as
+// before), waves 4-7 stage: the LDS image is double buffered, tile i + 1 is split and stored while tile i is contracted, and the
+// loads of tile i + 2 are issued right behind that store -- a whole tile before their use.  Rounds 2's form (256 threads, two blocks
+// per CU alternating) issued a tile's loads and waited for them at once: the ~2.4 us until a burst of loads from every CU has arrived
+// (igemm_bf16x3.hip) were paid per tile and covered only by the other block's MFMAs.
+__global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                       const WgX3Geom g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int stid = tid & 255;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int mh = wave & 1, cb = wave >> 1;                            // the wave's 32 rows and 32-channel block
+    const int mh = wave & 1, cb = (wave >> 1) & 1;                      // the consumer wave's 32 rows and 32-channel block
 
     const int per_slice = g.gx * g.gy;
     const int bid = blockIdx.x;
@@ -101,45 +108,120 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
     long tile1 = tile0 + g.tiles_per_block;
     tile1 = tile1 < ntiles ? tile1 : ntiles;
     if (tile0 >= tile1) return;
+    const int ntl = (int)(tile1 - tile0);
 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned d_lds0 = lds0, x_lds0 = lds0 + 2 * X3_DPLANE;
 
-    // ---- staging maps (tile-invariant) ----------------------------------------------------------------------------------------
-    // dY item i (2 per thread): row m = it >> 3, chunk = it & 7 -> tile row chunk >> 2, pixels 8 (chunk & 3) .. +7
-    unsigned dg_off[2], dl_off[2];
+    if (producer) {
+        // ================================================ PRODUCER ================================================
+        // ---- staging maps (tile-invariant; addresses of LDS buffer 0) ----
+        // dY item i (2 per thread): row m = it >> 3, chunk = it & 7 -> tile row chunk >> 2, pixels 8 (chunk & 3) .. +7
+        unsigned dg_off[2], dl_off[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int it = tid + 256 * i, m = it >> 3, ch = it & 7;
-        dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
-        dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
-    }
-    // X item i (3 per thread, 640 used): a 4-channel x 4-pixel register block = channel quad q8 of block cbs, patch row, chunk ck.
-    // Lane bits: q8 fastest, then the chunk.  A pixel is only 64 bytes, so the 16 lanes of a ds_write_b64 group cannot all hit
-    // different banks: with the 8 quads on consecutive lanes a group is 8 quads x 2 chunks (256 bytes apart) = 2-way, against 8-way
-    // with the chunks on consecutive lanes; a wave's global loads still cover 8 rows x 128 contiguous bytes per instruction.
-    unsigned xg_off[3], xl_off[3];
-    int x_row[3], x_ck[3];
+        for (int i = 0; i < 2; ++i) {
+            const int it = stid + 256 * i, m = it >> 3, ch = it & 7;
+            dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
+            dl_off[i] = lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
+        }
+        // X item i (3 per thread, 640 used): a 4-channel x 4-pixel register block = channel quad q8 of block cbs, patch row, chunk ck.
+        // Lane bits: q8 fastest, then the chunk.  A pixel is only 64 bytes, so the 16 lanes of a ds_write_b64 group cannot all hit
+        // different banks: with the 8 quads on consecutive lanes a group is 8 quads x 2 chunks (256 bytes apart) = 2-way, against 8-way
+        // with the chunks on consecutive lanes; a wave's global loads still cover 8 rows x 128 contiguous bytes per instruction.
+        unsigned xg_off[3], xl_off[3];
+        int x_row[3], x_ck[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int it = tid + 256 * i;
-        const int q8 = it & 7, cklo = (it >> 3) & 7, rest = it >> 6;     // rest 0..7: (cbs, row) with chunks 0..7; rest 8..9: chunks 8, 9 of all rows
-        int cbs, row, ck;
-        if (rest < 8) { cbs = rest & 1; row = rest >> 1; ck = cklo; }
-        else { cbs = rest & 1; row = cklo >> 1; ck = 8 + (cklo & 1); }
-        const bool use = rest < 10;
-        x_row[i] = use ? row : -1;
-        x_ck[i] = ck;
-        xg_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw + row * g.W + 4 * ck);
-        xl_off[i] = x_lds0 + (unsigned)cbs * X3_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+        for (int i = 0; i < 3; ++i) {
+            const int it = stid + 256 * i;
+            const int q8 = it & 7, cklo = (it >> 3) & 7, rest = it >> 6;     // rest 0..7: (cbs, row) with chunks 0..7; rest 8..9: chunks 8, 9 of all rows
+            int cbs, row, ck;
+            if (rest < 8) { cbs = rest & 1; row = rest >> 1; ck = cklo; }
+            else { cbs = rest & 1; row = cklo >> 1; ck = 8 + (cklo & 1); }
+            const bool use = rest < 10;
+            x_row[i] = use ? row : -1;
+            x_ck[i] = ck;
+            xg_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw + row * g.W + 4 * ck);
+            xl_off[i] = lds0 + 2 * X3_DPLANE + (unsigned)cbs * X3_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+        }
+        int tn, ty, tx;                                                  // load cursor
+        {
+            const long per_img = (long)g.tiles_y * g.tiles_x;
+            tn = (int)(tile0 / per_img);
+            const int r = (int)(tile0 - (long)tn * per_img);
+            ty = r / g.tiles_x;
+            tx = r - ty * g.tiles_x;
+        }
+        f32x4 dv[2][2], xv[3][4];
+        auto load_tile = [&]() {                                         // the cursor's tile -> registers; cursor + 1
+            const int y0 = ty * 2, x0 = tx * 32;
+            const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
+            const float* xsrc = x + ((long)tn * g.C + c0) * hw + (long)(y0 - 1) * g.W + (x0 - 4);
+            if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
+                dv[i][0] = *reinterpret_cast<const f32x4*>(p);
+                dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int iy = y0 - 1 + x_row[i], gx0 = x0 - 4 + 4 * x_ck[i];
+                const bool ok = x_row[i] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;      // zero padding: row / chunk outside
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xsrc + (long)c * hw) + xg_off[i]);
+                }
+            }
+        };
+        auto store_tile = [&](int buf) {                                 // registers -> (hi, lo) bf16 -> LDS buffer buf
+            const unsigned bo = (unsigned)buf * X3_LDS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split2(dv[i][0][0], dv[i][0][1], h0, l0);
+                split2(dv[i][0][2], dv[i][0][3], h1, l1);
+                split2(dv[i][1][0], dv[i][1][1], h2, l2);
+                split2(dv[i][1][2], dv[i][1][3], h3, l3);
+                const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                const unsigned da = dl_off[i] + bo;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (x_row[i] < 0) continue;
+                const unsigned xa = xl_off[i] + bo;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {                         // one pixel's four channels -> 8 bytes per plane
+                    unsigned h0, h1, l0, l1;
+                    split2(xv[i][0][px], xv[i][1][px], h0, l0);
+                    split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3_XPLANE) : "memory");
+                }
+            }
+        };
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        load_tile();                                                     // tile 0
+        store_tile(0);
+        if (ntl > 1) load_tile();                                        // tile 1
+        barrier();
+        for (int i = 0; i < ntl; ++i) {                                  // the consumers contract tile i out of buffer i & 1
+            if (i + 1 < ntl) store_tile((i + 1) & 1);                    // loaded a whole tile ago
+            if (i + 2 < ntl) load_tile();
+            barrier();
+        }
+        return;
     }
 
-    // ---- fragment addresses ---------------------------------------------------------------------------------------------------
+    // ==================================================== CONSUMER ====================================================
+    // ---- fragment addresses (LDS buffer 0) ----
     // A: row mh*32 + l31, pixels (row kb >> 1, 16 (kb & 1) + 8 lh + 0..7)
-    const unsigned a_addr = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
+    const unsigned a_addr0 = lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
     // B (transpose read): 16-lane group: channel half (lane >> 4) & 1, lane-in-group = 4 q + p supplies pixel row q, channels 4 p..+3
     const int gi = lane & 15, q4 = gi >> 2, p4 = gi & 3, chh = (lane >> 4) & 1;
-    const unsigned b_addr = x_lds0 + (unsigned)cb * X3_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
+    const unsigned b_addr0 = lds0 + 2 * X3_DPLANE + (unsigned)cb * X3_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
 
     f32x16 acc[9];
 #pragma unroll
@@ -147,69 +229,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    int tn, ty, tx;
-    {
-        const long per_img = (long)g.tiles_y * g.tiles_x;
-        tn = (int)(tile0 / per_img);
-        const int r = (int)(tile0 - (long)tn * per_img);
-        ty = r / g.tiles_x;
-        tx = r - ty * g.tiles_x;
-    }
-
-    for (long tile = tile0; tile < tile1; ++tile) {
-        const int y0 = ty * 2, x0 = tx * 32;
-        const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
-        const float* xsrc = x + ((long)tn * g.C + c0) * hw + (long)(y0 - 1) * g.W + (x0 - 4);
-        if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
-
-        // ---- stage: global -> registers -> (hi, lo) bf16 -> LDS ----
-        f32x4 dv[2][2], xv[3][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
-            dv[i][0] = *reinterpret_cast<const f32x4*>(p);
-            dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int iy = y0 - 1 + x_row[i], gx0 = x0 - 4 + 4 * x_ck[i];
-            const bool ok = x_row[i] >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;      // zero padding: row / chunk outside
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xsrc + (long)c * hw) + xg_off[i]);
-            }
-        }
-        if (tile != tile0) __syncthreads();                              // every wave has finished reading the previous tile
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-            split2(dv[i][0][0], dv[i][0][1], h0, l0);
-            split2(dv[i][0][2], dv[i][0][3], h1, l1);
-            split2(dv[i][1][0], dv[i][1][1], h2, l2);
-            split2(dv[i][1][2], dv[i][1][3], h3, l3);
-            const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
-            const unsigned da = dl_off[i];
-            asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (x_row[i] < 0) continue;
-            const unsigned xa = xl_off[i];
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {                             // one pixel's four channels -> 8 bytes per plane
-                unsigned h0, h1, l0, l1;
-                split2(xv[i][0][px], xv[i][1][px], h0, l0);
-                split2(xv[i][2][px], xv[i][3][px], h1, l1);
-                const u32x2 hi = {h0, h1}, lo = {l0, l1};
-                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
-                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3_XPLANE) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-
+    asm volatile("s_barrier" ::: "memory");                             // tile 0 staged
+    for (int it = 0; it < ntl; ++it) {
+        const unsigned a_addr = a_addr0 + (unsigned)(it & 1) * X3_LDS, b_addr = b_addr0 + (unsigned)(it & 1) * X3_LDS;
         // ---- contraction: 4 k-blocks of 16 pixels x 9 taps x 3 split products ----
         // Twelve sub-steps (k-block kb, kernel row kh), each 9 MFMAs on fragment set s & 1 with the 12 transpose reads (+ the two dY
         // reads of a new k-block) of sub-step s + 1 issued two per MFMA gap into the other set (round 3; before, a sub-step's reads were
@@ -256,11 +278,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const float* __restric
                 });
             });
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every read of this buffer retired; the next tile is staged
     }
 
     // ---- epilogue: accumulators [m][channel] per tap -> dW order [m][c][t] through LDS, contiguous atomics ----
     // per wave and pass: 8 rows x 32 channels x 9 taps = 2304 floats (9216 B); the four waves use disjoint regions
-    __syncthreads();
     float* stage = reinterpret_cast<float*>(smem) + wave * 2304;
     const long col_base = (long)(c0 + cb * 32) * g.wsc;
 #pragma unroll
@@ -553,13 +575,13 @@ int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, in
     g.tiles_x = OW / 32; g.tiles_y = OH / 2;
     g.gx = C / 64; g.gy = M / 64;
     const long ntiles = (long)N * g.tiles_y * g.tiles_x;
-    long slices = 512 / ((long)g.gx * g.gy);
+    long slices = 256 / ((long)g.gx * g.gy);                             // one 512-thread block per CU
     if (slices < 1) slices = 1;
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    lds_optin((const void*)wgrad_x3_kernel, X3_LDS);
-    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(256), X3_LDS, s, x, dy, dw, g);
+    lds_optin((const void*)wgrad_x3_kernel, 2 * X3_LDS);
+    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g);
     const int rc = check_launch("wgrad_x3");
     return rc == FAOCTASR_OK ? 1 : rc;
 }

@@ -588,6 +588,30 @@ def test_conv2d_bf16x3(fa, case):
     close(out, ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()))
 
 
+def test_conv2d_bf16x3_unaligned_operands(fa):
+    """The round-3 bf16x3 kernel stages 16-byte pieces (buffer_load_dwordx4 of 4 pixels, global_store_dwordx4 of 4 outputs) when the
+    tensors allow it; an activation or output that starts at an odd float must take the single-pixel / single-dword forms and give
+    the same numbers (igemm_bf16x3.hip: sp_quad_ok, `wide`)."""
+    g = torch.Generator().manual_seed(77)
+    N, C, H, W, M = 2, 32, 24, 64, 64
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(M, C, 3, 3, generator=g) * 0.05
+    ref = F.conv2d(x, w, None, padding=1)
+    fa.ops.conv_precision = 2
+    try:
+        with torch.no_grad():
+            aligned = fa.ops.conv2d(dev(x), dev(w), None, 1, 1, False, None, 0.2)
+            flat = torch.zeros(x.numel() + 1, device="cuda")
+            flat[1:].copy_(dev(x).reshape(-1))
+            xo = flat[1:].view(N, C, H, W)                      # 4 bytes past a 16-byte boundary
+            assert xo.data_ptr() % 16 == 4 and xo.is_contiguous()
+            shifted = fa.ops.conv2d(xo, dev(w), None, 1, 1, False, None, 0.2)
+    finally:
+        fa.ops.conv_precision = 0
+    assert rel_l2(aligned, ref) < 3e-5
+    assert torch.equal(aligned, shifted)                        # same products, same order: bit-identical
+
+
 @pytest.mark.parametrize("case", [c for c in CONVT_CASES if c[1] >= 16 and c[3] >= 24])
 def test_conv_transpose2d_bf16x3(fa, case):
     N, C, H, W, M, k, s, p, op, bias = case
