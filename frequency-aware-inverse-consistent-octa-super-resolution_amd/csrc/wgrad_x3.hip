@@ -329,12 +329,15 @@ struct WgX3RowGeom {
 };
 
 template <int KW>
-__global__ __launch_bounds__(256, 2) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                              const WgX3RowGeom g) {
+__global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                                           const WgX3RowGeom g) {
+    // wave-specialised like wgrad_x3_kernel (round 3): waves 0-3 contract, waves 4-7 stage into a double-buffered LDS image, a tile ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int stid = tid & 255;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int mh = wave & 1, cb = wave >> 1;
+    const int mh = wave & 1, cb = (wave >> 1) & 1;
 
     const int per_slice = g.gx * g.gy * g.KH;
     const int bid = blockIdx.x;
@@ -358,37 +361,126 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_row_kernel(const float* __res
     long tile1 = tile0 + g.tiles_per_block;
     tile1 = tile1 < ntiles ? tile1 : ntiles;
     if (tile0 >= tile1) return;
+    const int ntl = (int)(tile1 - tile0);
 
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     const unsigned d_lds0 = lds0, x_lds0 = lds0 + 2 * X3_DPLANE;
 
-    unsigned dg_off[2], dl_off[2];
+    if (producer) {
+        unsigned dg_off[2], dl_off[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int it = tid + 256 * i, m = it >> 3, ch = it & 7;
-        dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
-        dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
-    }
-    // X item i (2 per thread, 320 used): channel quad q8 of block cbs, patch row, chunk ck; lane bits: q8 fastest, then the chunk
-    unsigned xc_off[2], xl_off[2];
-    int x_row[2], x_ck[2];
+        for (int i = 0; i < 2; ++i) {
+            const int it = stid + 256 * i, m = it >> 3, ch = it & 7;
+            dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
+            dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
+        }
+        // X item i (2 per thread, 320 used): channel quad q8 of block cbs, patch row, chunk ck; lane bits: q8 fastest, then the chunk
+        unsigned xc_off[2], xl_off[2];
+        int x_row[2], x_ck[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int it = tid + 256 * i;
-        const int q8 = it & 7, cklo = (it >> 3) & 7, rest2 = it >> 6;     // rest2 0..3: (cbs, row) with chunks 0..7; rest2 4: chunks 8, 9 of all (cbs, row)
-        int cbs, row, ck;
-        if (rest2 < 4) { cbs = rest2 & 1; row = rest2 >> 1; ck = cklo; }
-        else { cbs = cklo & 1; row = (cklo >> 1) & 1; ck = 8 + (cklo >> 2); }
-        const bool use = rest2 < 5;
-        x_row[i] = use ? row : -1;
-        x_ck[i] = ck;
-        xc_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw);      // channel part; row / column are resolved per tile (padding)
-        xl_off[i] = x_lds0 + (unsigned)cbs * X3R_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+        for (int i = 0; i < 2; ++i) {
+            const int it = stid + 256 * i;
+            const int q8 = it & 7, cklo = (it >> 3) & 7, rest2 = it >> 6;     // rest2 0..3: (cbs, row) with chunks 0..7; rest2 4: chunks 8, 9 of all (cbs, row)
+            int cbs, row, ck;
+            if (rest2 < 4) { cbs = rest2 & 1; row = rest2 >> 1; ck = cklo; }
+            else { cbs = cklo & 1; row = (cklo >> 1) & 1; ck = 8 + (cklo >> 2); }
+            const bool use = rest2 < 5;
+            x_row[i] = use ? row : -1;
+            x_ck[i] = ck;
+            xc_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw);      // channel part; row / column are resolved per tile (padding)
+            xl_off[i] = x_lds0 + (unsigned)cbs * X3R_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+        }
+        int tn, ty, tx;                                                  // load cursor
+        {
+            const long per_img = (long)g.tiles_y * g.tiles_x;
+            tn = (int)(tile0 / per_img);
+            const int r = (int)(tile0 - (long)tn * per_img);
+            ty = r / g.tiles_x;
+            tx = r - ty * g.tiles_x;
+        }
+        f32x4 dv[2][2], xv[2][4];
+        int flip[2] = {0, 0};
+        auto load_tile = [&]() {
+            const int y0 = ty * 2, x0 = tx * 32;
+            const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
+            const float* ximg = x + ((long)tn * g.C + c0) * hw;
+            if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
+                dv[i][0] = *reinterpret_cast<const f32x4*>(p);
+                dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int iy = y0 + x_row[i] + kh - g.pad, gx0 = x0 - 4 + 4 * x_ck[i];
+                bool ok = x_row[i] >= 0;
+                flip[i] = 0;
+                if (g.reflect) {
+                    iy = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
+                    if (gx0 < 0) { gx0 = 0; flip[i] = 1; }
+                    else if (gx0 >= g.W) { gx0 = g.W - 4; flip[i] = 2; }
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ximg + (long)c * hw + (long)iy * g.W + gx0) + xc_off[i]);
+                }
+            }
+        };
+        auto store_tile = [&](int buf) {
+            const unsigned bo = (unsigned)buf * X3R_LDS;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+                split2(dv[i][0][0], dv[i][0][1], h0, l0);
+                split2(dv[i][0][2], dv[i][0][3], h1, l1);
+                split2(dv[i][1][0], dv[i][1][1], h2, l2);
+                split2(dv[i][1][2], dv[i][1][3], h3, l3);
+                const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
+                const unsigned da = dl_off[i] + bo;
+                asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (x_row[i] < 0) continue;
+                const unsigned xa = xl_off[i] + bo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                            // mirrored border chunks (reflection only)
+                    const f32x4 v = xv[i][c];
+                    const f32x4 l = {v[0], v[3], v[2], v[1]}, r = {v[2], v[1], v[0], v[3]};
+                    xv[i][c] = flip[i] == 1 ? l : (flip[i] == 2 ? r : v);
+                }
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    unsigned h0, h1, l0, l1;
+                    split2(xv[i][0][px], xv[i][1][px], h0, l0);
+                    split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                    const u32x2 hi = {h0, h1}, lo = {l0, l1};
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3R_XPLANE) : "memory");
+                }
+            }
+        };
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        load_tile();                                                     // tile 0
+        store_tile(0);
+        if (ntl > 1) load_tile();                                        // tile 1
+        barrier();
+        for (int i = 0; i < ntl; ++i) {                                  // the consumers contract tile i out of buffer i & 1
+            if (i + 1 < ntl) store_tile((i + 1) & 1);
+            if (i + 2 < ntl) load_tile();
+            barrier();
+        }
+        return;
     }
 
-    const unsigned a_addr = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
+    const unsigned a_addr0 = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
     const int gi = lane & 15, q4 = gi >> 2, p4 = gi & 3, chh = (lane >> 4) & 1;
-    const unsigned b_addr = x_lds0 + (unsigned)cb * X3R_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
+    const unsigned b_addr0 = x_lds0 + (unsigned)cb * X3R_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
 
     f32x16 acc[KW];
 #pragma unroll
@@ -396,83 +488,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_row_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    int tn, ty, tx;
-    {
-        const long per_img = (long)g.tiles_y * g.tiles_x;
-        tn = (int)(tile0 / per_img);
-        const int r = (int)(tile0 - (long)tn * per_img);
-        ty = r / g.tiles_x;
-        tx = r - ty * g.tiles_x;
-    }
-
-    for (long tile = tile0; tile < tile1; ++tile) {
-        const int y0 = ty * 2, x0 = tx * 32;
-        const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
-        const float* ximg = x + ((long)tn * g.C + c0) * hw;
-        if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
-
-        f32x4 dv[2][2], xv[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* p = reinterpret_cast<const char*>(dsrc) + dg_off[i];
-            dv[i][0] = *reinterpret_cast<const f32x4*>(p);
-            dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
-        }
-        int flip[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int iy = y0 + x_row[i] + kh - g.pad, gx0 = x0 - 4 + 4 * x_ck[i];
-            bool ok = x_row[i] >= 0;
-            flip[i] = 0;
-            if (g.reflect) {
-                iy = iy < 0 ? -iy : (iy >= g.H ? 2 * g.H - 2 - iy : iy);
-                if (gx0 < 0) { gx0 = 0; flip[i] = 1; }
-                else if (gx0 >= g.W) { gx0 = g.W - 4; flip[i] = 2; }
-            } else {
-                ok = ok && (unsigned)iy < (unsigned)g.H && (unsigned)gx0 < (unsigned)g.W;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xv[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok) xv[i][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ximg + (long)c * hw + (long)iy * g.W + gx0) + xc_off[i]);
-            }
-        }
-        if (tile != tile0) __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-            split2(dv[i][0][0], dv[i][0][1], h0, l0);
-            split2(dv[i][0][2], dv[i][0][3], h1, l1);
-            split2(dv[i][1][0], dv[i][1][1], h2, l2);
-            split2(dv[i][1][2], dv[i][1][3], h3, l3);
-            const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
-            const unsigned da = dl_off[i];
-            asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
-            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (x_row[i] < 0) continue;
-            const unsigned xa = xl_off[i];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {                                // mirrored border chunks (reflection only)
-                const f32x4 v = xv[i][c];
-                const f32x4 l = {v[0], v[3], v[2], v[1]}, r = {v[2], v[1], v[0], v[3]};
-                xv[i][c] = flip[i] == 1 ? l : (flip[i] == 2 ? r : v);
-            }
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                unsigned h0, h1, l0, l1;
-                split2(xv[i][0][px], xv[i][1][px], h0, l0);
-                split2(xv[i][2][px], xv[i][3][px], h1, l1);
-                const u32x2 hi = {h0, h1}, lo = {l0, l1};
-                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
-                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3R_XPLANE) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-
+    asm volatile("s_barrier" ::: "memory");                             // tile 0 staged
+    for (int it = 0; it < ntl; ++it) {
+        const unsigned a_addr = a_addr0 + (unsigned)(it & 1) * X3R_LDS, b_addr = b_addr0 + (unsigned)(it & 1) * X3R_LDS;
         // ---- contraction: 4 k-blocks of 16 pixels x KW taps x 3 split products ----
         x3_static_for<0, 4>([&](auto kc) {
             constexpr int kb = decltype(kc)::value;
@@ -511,10 +529,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_row_kernel(const float* __res
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, d, 0, 0, 0);
             }
         });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every read of this buffer retired; the next tile is staged
     }
 
     // ---- epilogue: [m][channel] per tap -> dW[m][c][kh][0..KW) through LDS, atomics in runs of KW floats per channel ----
-    __syncthreads();
     float* stage = reinterpret_cast<float*>(smem) + wave * (8 * 32 * KW);
     const long col_base = (long)(c0 + cb * 32) * g.wsc + (long)kh * KW;
 #pragma unroll
@@ -551,14 +569,14 @@ static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N
     g.tiles_x = IW / 32; g.tiles_y = IH / 2;
     g.gx = C / 64; g.gy = M / 64;
     const long ntiles = (long)N * g.tiles_y * g.tiles_x;
-    long slices = 512 / ((long)g.gx * g.gy * KH);
+    long slices = 256 / ((long)g.gx * g.gy * KH);                        // one 512-thread block per CU
     if (slices < 1) slices = 1;
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
     auto k = wgrad_x3_row_kernel<7>;
-    lds_optin((const void*)k, X3R_LDS);
-    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * KH * g.slices)), dim3(256), X3R_LDS, s, x, dy, dw, g);
+    lds_optin((const void*)k, 2 * X3R_LDS);
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * KH * g.slices)), dim3(512), 2 * X3R_LDS, s, x, dy, dw, g);
     const int rc = check_launch("wgrad_x3_row");
     return rc == FAOCTASR_OK ? 1 : rc;
 }
