@@ -23,6 +23,12 @@
 #include <cstdint>
 #include <type_traits>
 
+#ifndef SP_SPLIT_BELOW
+#define SP_SPLIT_BELOW 128        // grids with fewer blocks split the channel groups over the grid's z (atomics into a zeroed output).
+                                  // Half a chip of blocks stays unsplit: the 256 -> 256 @32^2 layer alone is slower so (56 vs 46 us), the
+                                  // step is faster (118.4 -> 121.8 img/s, two runs each): no memset, no 16 MB of fp32 atomics per call,
+                                  // 16-byte epilogue stores, and the two generator chains' kernels share the chip
+#endif
 #ifndef SP_WIDE
 #define SP_WIDE 1                 // 0: one dword store per accumulator register (round 1/2)
 #endif
@@ -766,7 +772,7 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     const long blocks = mx * gy * g.nphase;
     int ksplit = 1;
     const int ngroups = (g.C + 15) / 16;
-    if (g.act == FAOCTASR_ACT_NONE && blocks < 256) {                   // one block per CU: fill the chip
+    if (g.act == FAOCTASR_ACT_NONE && blocks < SP_SPLIT_BELOW) {        // one block per CU: fill the chip
         ksplit = (int)(256 / blocks);
         if (ksplit > ngroups / 2) ksplit = ngroups / 2;
         ksplit = ksplit < 1 ? 1 : ksplit;
