@@ -390,7 +390,7 @@ def main():
         ts.precision = "f32"
         extra["alt_precision_bf16x3"] = {"value": round(B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3),
                                          "dtype": "conv fwd+dgrad on bf16 MFMA with hi/lo-split operands (3 MFMAs per product, fp32 accumulate); "
-                                                  "likewise the 3x3 / 7x7 stride-1 weight gradients; stride-2, transposed, narrow-map layers and everything else f32",
+                                                  "likewise the weight gradients of the 3x3 / 7x7 stride-1, 3x3 / 4x4 stride-2 and stride-2 transposed layers; narrow maps (< 24 wide), the 1-channel stem / head and everything else f32",
                                          "parity": "step-0 losses within 1e-4, gradient norms within 2.3e-4 of the f32 path (tests/test_gpu_step.py)"}
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
     # (data-parallel: every rank captures and replays in lockstep, RCCL's kernels are graph nodes -- opt-in with --ddp-graph)
@@ -427,7 +427,7 @@ def main():
         line = {"metric": "train-step images/sec (G+D fwd+bwd) on 256x256 OCTA", "value": round(value, 3), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 split MFMA (conv fwd+dgrad, 3x3/7x7 stride-1 wgrad), f32 elsewhere", "data": "synthetic",
+                "dtype": "f32" if args.precision == "f32" else "f32 via bf16x3 split MFMA (conv fwd+dgrad+wgrad on maps >= 24 wide), f32 elsewhere", "data": "synthetic",
                 "config": {"workload": "%dx%dx1 OCTA pairs, batch %d per GPU, fp32, full G+D train step "
                                        "(4 frequency splits, 6 G fwd, 6 D fwd, 3 backward, 2 AdamW)" % (H, H, B),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "loss_G": round(loss_G, 5),

@@ -674,7 +674,6 @@ int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, 
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,
                                     int KW, int stride, int pad, int out_pad, int accumulate, int precision, faoctasr_stream_t stream) {
-    (void)precision;               // (the transposed layers of the model are stride 2: fp32 kernels only, for now)
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;
@@ -684,6 +683,10 @@ int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, 
     if (IW >= 24) {
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
+        if (precision == 2) {      // split-precision operands on the bf16 MFMA (stride-2 row kernel with x / dy swapped)
+            rc = launch_wgrad_x3(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW, (hipStream_t)stream);
+            if (rc != 0) { set_route(ROUTE_WGRAD_X3); return rc < 0 ? rc : FAOCTASR_OK; }
+        }
         rc = launch_wgrad_s1(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,
                              (hipStream_t)stream);
         if (rc != 0) { set_route(ROUTE_WGRAD_S1); return rc < 0 ? rc : FAOCTASR_OK; }

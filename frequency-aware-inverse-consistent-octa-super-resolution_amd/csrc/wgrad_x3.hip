@@ -315,20 +315,27 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
 // Reflection: a mirrored ROW is a redirected source row; a border chunk (image columns -4..-1 or W..W+3) is the neighbouring
 // chunk with its four pixels permuted (out[q] = in[4-q] left, in[2-q] right: pad <= 3, so the one pixel this cannot supply is
 // never read), exactly as wgrad_s1.hip does.
+// Stride 2 (round 3: the 4x4 and 3x3 stride-2 convolutions and, with x / dy swapped, the stride-2 transposed ones): the patch row is
+// 72 columns (output x at tap kw reads patch column 2 x + kw - pad + 4 <= 62 + KW + 3 - pad), the two patch rows are input rows
+// 2 (y0 + r) + kh - pad, and a lane's transpose-read address advances two pixels per k index -- everything else is unchanged.
 constexpr int X3R_PROWS = 2;
-constexpr int X3R_PPIX = X3R_PROWS * X3_PCOLS;          // 80 pixels per channel block
-constexpr unsigned X3R_CB_BYTES = X3R_PPIX * 64;
-constexpr unsigned X3R_XPLANE = 2 * X3R_CB_BYTES;
-constexpr unsigned X3R_LDS = 2 * X3_DPLANE + 2 * X3R_XPLANE;      // 18432 + 20480 = 38912
+template <int S> struct X3R {
+    static constexpr int PCOLS = S == 1 ? X3_PCOLS : 72;             // patch columns: 4-pixel chunks [S x0 - 4, ...)
+    static constexpr int NCK = PCOLS / 4;
+    static constexpr unsigned CB_BYTES = X3R_PROWS * PCOLS * 64;     // one 32-channel block of one plane
+    static constexpr unsigned XPLANE = 2 * CB_BYTES;
+    static constexpr unsigned LDS = 2 * X3_DPLANE + 2 * XPLANE;      // S = 1: 18432 + 20480 = 38912; S = 2: 18432 + 36864 = 55296
+    static constexpr int NXI = (2 * 8 * X3R_PROWS * NCK + 255) / 256;   // X items per staging thread: 2 / 3
+};
 
 struct WgX3RowGeom {
-    int N, C, H, W, M, KH, pad, reflect;
+    int N, C, H, W, OH, OW, M, KH, pad, reflect;     // x: C x H x W, dy: M x OH x OW
     long wsm, wsc;           // dW element strides of row m / channel c (KH*KW taps contiguous)
     int tiles_x, tiles_y, tiles_per_block;
     int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges (x KH kernel rows)
 };
 
-template <int KW>
+template <int KW, int S, int PAD>
 __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
                                                            const WgX3RowGeom g) {
     // wave-specialised like wgrad_x3_kernel (round 3): waves 0-3 contract, waves 4-7 stage into a double-buffered LDS image, a tile ahead
@@ -355,7 +362,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     const int kh = inner % g.KH;
     const int rest = inner / g.KH;
     const int c0 = (rest % g.gx) * 64, m0 = (rest / g.gx) * 64;
-    const long hw = (long)g.H * g.W;
+    const long hw = (long)g.H * g.W, ohw = (long)g.OH * g.OW;
+    typedef X3R<S> R;
     const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
     const long tile0 = (long)slice * g.tiles_per_block;
     long tile1 = tile0 + g.tiles_per_block;
@@ -371,24 +379,22 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int it = stid + 256 * i, m = it >> 3, ch = it & 7;
-            dg_off[i] = 4u * (unsigned)(m * (int)hw + (ch >> 2) * g.W + (ch & 3) * 8);
+            dg_off[i] = 4u * (unsigned)(m * (int)ohw + (ch >> 2) * g.OW + (ch & 3) * 8);
             dl_off[i] = d_lds0 + 2u * (unsigned)(m * X3_DLD + (ch >> 2) * 32 + (ch & 3) * 8);
         }
-        // X item i (2 per thread, 320 used): channel quad q8 of block cbs, patch row, chunk ck; lane bits: q8 fastest, then the chunk
-        unsigned xc_off[2], xl_off[2];
-        int x_row[2], x_ck[2];
+        // X item i (R::NXI per thread): channel quad q8 of block cbs, patch row, chunk ck; lane bits: q8 fastest, then the chunk
+        unsigned xc_off[R::NXI], xl_off[R::NXI];
+        int x_row[R::NXI], x_ck[R::NXI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < R::NXI; ++i) {
             const int it = stid + 256 * i;
-            const int q8 = it & 7, cklo = (it >> 3) & 7, rest2 = it >> 6;     // rest2 0..3: (cbs, row) with chunks 0..7; rest2 4: chunks 8, 9 of all (cbs, row)
-            int cbs, row, ck;
-            if (rest2 < 4) { cbs = rest2 & 1; row = rest2 >> 1; ck = cklo; }
-            else { cbs = cklo & 1; row = (cklo >> 1) & 1; ck = 8 + (cklo >> 2); }
-            const bool use = rest2 < 5;
-            x_row[i] = use ? row : -1;
+            const int q8 = it & 7, rem = it >> 3;
+            const int ck = rem % R::NCK, rc = rem / R::NCK;              // rc = row * 2 + cbs
+            const int cbs = rc & 1, row = (rc >> 1) & 1;
+            x_row[i] = rc < 4 ? row : -1;
             x_ck[i] = ck;
             xc_off[i] = 4u * (unsigned)((cbs * 8 + q8) * 4 * (int)hw);      // channel part; row / column are resolved per tile (padding)
-            xl_off[i] = x_lds0 + (unsigned)cbs * X3R_CB_BYTES + (unsigned)(row * X3_PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
+            xl_off[i] = x_lds0 + (unsigned)cbs * R::CB_BYTES + (unsigned)(row * R::PCOLS + 4 * ck) * 64u + (unsigned)q8 * 8u;
         }
         int tn, ty, tx;                                                  // load cursor
         {
@@ -398,11 +404,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
             ty = r / g.tiles_x;
             tx = r - ty * g.tiles_x;
         }
-        f32x4 dv[2][2], xv[2][4];
-        int flip[2] = {0, 0};
+        f32x4 dv[2][2], xv[R::NXI][4];
+        int flip[R::NXI] = {};
         auto load_tile = [&]() {
             const int y0 = ty * 2, x0 = tx * 32;
-            const float* dsrc = dy + ((long)tn * g.M + m0) * hw + (long)y0 * g.W + x0;
+            const float* dsrc = dy + ((long)tn * g.M + m0) * ohw + (long)y0 * g.OW + x0;
             const float* ximg = x + ((long)tn * g.C + c0) * hw;
             if (++tx == g.tiles_x) { tx = 0; if (++ty == g.tiles_y) { ty = 0; ++tn; } }
 #pragma unroll
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                 dv[i][1] = *reinterpret_cast<const f32x4*>(p + 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int iy = y0 + x_row[i] + kh - g.pad, gx0 = x0 - 4 + 4 * x_ck[i];
+            for (int i = 0; i < R::NXI; ++i) {
+                int iy = S * (y0 + x_row[i]) + kh - PAD, gx0 = S * x0 - 4 + 4 * x_ck[i];
                 bool ok = x_row[i] >= 0;
                 flip[i] = 0;
                 if (g.reflect) {
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
             }
         };
         auto store_tile = [&](int buf) {
-            const unsigned bo = (unsigned)buf * X3R_LDS;
+            const unsigned bo = (unsigned)buf * R::LDS;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(da), "v"(lo), "n"(X3_DPLANE) : "memory");
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < R::NXI; ++i) {
                 if (x_row[i] < 0) continue;
                 const unsigned xa = xl_off[i] + bo;
 #pragma unroll
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                     split2(xv[i][2][px], xv[i][3][px], h1, l1);
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
-                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3R_XPLANE) : "memory");
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + R::XPLANE) : "memory");
                 }
             }
         };
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 
     const unsigned a_addr0 = d_lds0 + 2u * (unsigned)((mh * 32 + l31) * X3_DLD + 8 * lh);
     const int gi = lane & 15, q4 = gi >> 2, p4 = gi & 3, chh = (lane >> 4) & 1;
-    const unsigned b_addr0 = x_lds0 + (unsigned)cb * X3R_CB_BYTES + (unsigned)(8 * lh + q4) * 64u + (unsigned)(chh * 4 + p4) * 8u;
+    const unsigned b_addr0 = x_lds0 + (unsigned)cb * R::CB_BYTES + (unsigned)(S * (8 * lh + q4)) * 64u + (unsigned)(chh * 4 + p4) * 8u;
 
     f32x16 acc[KW];
 #pragma unroll
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 
     asm volatile("s_barrier" ::: "memory");                             // tile 0 staged
     for (int it = 0; it < ntl; ++it) {
-        const unsigned a_addr = a_addr0 + (unsigned)(it & 1) * X3R_LDS, b_addr = b_addr0 + (unsigned)(it & 1) * X3R_LDS;
+        const unsigned a_addr = a_addr0 + (unsigned)(it & 1) * R::LDS, b_addr = b_addr0 + (unsigned)(it & 1) * R::LDS;
         // ---- contraction: 4 k-blocks of 16 pixels x KW taps x 3 split products ----
         x3_static_for<0, 4>([&](auto kc) {
             constexpr int kb = decltype(kc)::value;
@@ -501,14 +507,14 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
             bf16x4 bh[KW][2], bl[KW][2];
             x3_static_for<0, KW>([&](auto wc) {
                 constexpr int kw = decltype(wc)::value;
-                // pixel of k index j: patch row kb >> 1, column 16 (kb & 1) + j + kw + (4 - pad); pad = (KW - 1) / 2
-                constexpr unsigned imm = (unsigned)((kb >> 1) * X3_PCOLS + 16 * (kb & 1) + kw + (4 - (KW - 1) / 2)) * 64u;
+                // pixel of k index j: patch row kb >> 1, column S (16 (kb & 1) + j) + kw + 4 - pad
+                constexpr unsigned imm = (unsigned)((kb >> 1) * R::PCOLS + S * 16 * (kb & 1) + kw + (4 - PAD)) * 64u;
                 const unsigned ba = b_addr;                              // (asm operands cannot name a captured variable / array element)
                 bf16x4 h0, h1, l0, l1;
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h0) : "v"(ba), "n"(imm));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h1) : "v"(ba), "n"(imm + 4 * 64));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l0) : "v"(ba), "n"(imm + X3R_XPLANE));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l1) : "v"(ba), "n"(imm + 4 * 64 + X3R_XPLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h1) : "v"(ba), "n"(imm + S * 4 * 64));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l0) : "v"(ba), "n"(imm + R::XPLANE));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l1) : "v"(ba), "n"(imm + S * 4 * 64 + R::XPLANE));
                 bh[kw][0] = h0; bh[kw][1] = h1; bl[kw][0] = l0; bl[kw][1] = l1;
             });
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_hi), "+v"(a_lo));
@@ -558,33 +564,46 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     }
 }
 
-static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW, int pad,
-                               int reflect, long wsm, long wsc, hipStream_t s) {
-    if (KH != 7 || KW != 7 || pad != 3) return 0;                        // (KW is a template parameter; 7x7 is what the path has)
-    if ((C & 63) || (M & 63) || (IW & 31) || (IH & 1) || wsc != (long)KH * KW) return 0;
-    if (reflect && (IH <= pad || IW < 8)) return 0;
-    if ((long)64 * IH * IW >= (1L << 29)) return 0;
-    WgX3RowGeom g;
-    g.N = N; g.C = C; g.H = IH; g.W = IW; g.M = M; g.KH = KH; g.pad = pad; g.reflect = reflect; g.wsm = wsm; g.wsc = wsc;
-    g.tiles_x = IW / 32; g.tiles_y = IH / 2;
-    g.gx = C / 64; g.gy = M / 64;
-    const long ntiles = (long)N * g.tiles_y * g.tiles_x;
-    long slices = 256 / ((long)g.gx * g.gy * KH);                        // one 512-thread block per CU
+template <int KW, int S, int PAD>
+static int x3_row_go(const float* x, const float* dy, float* dw, WgX3RowGeom& g, hipStream_t s) {
+    const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
+    long slices = 256 / ((long)g.gx * g.gy * g.KH);                      // one 512-thread block per CU
     if (slices < 1) slices = 1;
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    auto k = wgrad_x3_row_kernel<7>;
-    lds_optin((const void*)k, 2 * X3R_LDS);
-    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * KH * g.slices)), dim3(512), 2 * X3R_LDS, s, x, dy, dw, g);
+    auto k = wgrad_x3_row_kernel<KW, S, PAD>;
+    const size_t lds = 2 * (size_t)X3R<S>::LDS > (size_t)4 * 8 * 32 * KW * 4 ? 2 * (size_t)X3R<S>::LDS : (size_t)4 * 8 * 32 * KW * 4;
+    lds_optin((const void*)k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.KH * g.slices)), dim3(512), lds, s, x, dy, dw, g);
     const int rc = check_launch("wgrad_x3_row");
     return rc == FAOCTASR_OK ? 1 : rc;
+}
+
+// one kernel row per block: 7x7 pad 3 stride 1 ("same", reflection or zero padding); 4x4 and 3x3 pad 1 stride 2 (zero padding, IH = 2 OH)
+static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
+                               int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
+    if (KH != KW || (C & 63) || (M & 63) || (OW & 31) || (OH & 1) || (IW & 3) || wsc != (long)KH * KW) return 0;
+    if ((long)64 * IH * IW >= (1L << 29) || (long)64 * OH * OW >= (1L << 29)) return 0;      // 32-bit byte offsets inside a 64-channel slab
+    WgX3RowGeom g;
+    g.N = N; g.C = C; g.H = IH; g.W = IW; g.OH = OH; g.OW = OW; g.M = M; g.KH = KH; g.pad = pad; g.reflect = reflect; g.wsm = wsm; g.wsc = wsc;
+    g.tiles_x = OW / 32; g.tiles_y = OH / 2;
+    g.gx = C / 64; g.gy = M / 64;
+    if (stride == 1 && KH == 7 && pad == 3 && OH == IH && OW == IW) {
+        if (reflect && (IH <= pad || IW < 8)) return 0;
+        return x3_row_go<7, 1, 3>(x, dy, dw, g, s);
+    }
+    if (stride == 2 && pad == 1 && !reflect && IH == 2 * OH && IW == 2 * OW) {
+        if (KH == 4) return x3_row_go<4, 2, 1>(x, dy, dw, g, s);
+        if (KH == 3) return x3_row_go<3, 2, 1>(x, dy, dw, g, s);
+    }
+    return 0;
 }
 
 // returns 1 when launched, 0 when the shape is left to the fp32 kernels, <0 on error.  dw zeroed / accumulating, as elsewhere.
 int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
-    if (stride == 1 && KH == 7 && OH == IH && OW == IW) return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, KH, KW, pad, reflect, wsm, wsc, s);
+    if ((stride == 1 && KH == 7) || stride == 2) return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, wsm, wsc, s);
     if (stride != 1 || KH != 3 || KW != 3 || pad != 1 || reflect || OH != IH || OW != IW) return 0;
     if ((C & 63) || (M & 63) || (OW & 31) || (OH & 1) || wsc != 9) return 0;
     if ((long)64 * IH * IW >= (1L << 29)) return 0;                      // 32-bit byte offsets inside a 64-channel slab

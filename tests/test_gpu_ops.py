@@ -81,6 +81,10 @@ CONV_CASES = [
     # stride-2 4x4 weight gradient through wgrad_s1.hip (S = 2): output map 32 / 64 / 96 wide, top / bottom / left / right borders
     (2, 16, 12, 64, 64, 4, 2, 1, False, True, None),          # one tile column, 3 tile rows (6 output rows)
     (2, 24, 64, 192, 128, 4, 2, 1, False, False, None),       # 3 tile columns (border, interior, border), two row blocks, 384 columns
+    # bf16x3 weight gradient of the stride-2 layers (wgrad_x3.hip row kernel, S = 2): 4x4 and 3x3, one / three tile columns, M and C slabs
+    (2, 64, 8, 64, 64, 4, 2, 1, False, True, None),           # one tile column (left and right border in one tile), 2 tile rows
+    (2, 64, 16, 192, 128, 4, 2, 1, False, False, None),       # three tile columns, two row blocks
+    (3, 128, 12, 128, 64, 3, 2, 1, False, False, None),       # 3x3 stride 2, two 64-channel slabs, odd batch
     # 4x4 stride-2 stems with 1..4 input channels: VALU input / weight gradient (conv_stem.hip)
     (3, 1, 20, 44, 128, 4, 2, 1, False, False, None),         # ragged 10 x 22 map (partial tile rows and columns), M = 128
     (2, 2, 36, 72, 42, 4, 2, 1, False, True, None),           # C = 2, M not a multiple of the channel group
@@ -576,7 +580,9 @@ def test_conv2d_bf16x3(fa, case):
     assert rel_l2(xd.grad, xr.grad) < 3e-5
     # the weight gradient: split-precision kernel (route 15) on the stride-1 3x3 layers with C, M % 64 == 0, W % 32 == 0, even H
     # ... and on the 7x7 pad-3 layers, reflection or zero padding, one kernel row per block (wgrad_x3_row_kernel)
+    # ... and (round 3) on the 4x4 / 3x3 pad-1 stride-2 layers with an output map a multiple of 32 wide (the row kernel at S = 2)
     x3 = s == 1 and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0 and ((k == 3 and p == 1 and not reflect) or (k == 7 and p == 3))
+    x3 = x3 or (s == 2 and k in (3, 4) and p == 1 and not reflect and C % 64 == 0 and M % 64 == 0 and H % 4 == 0 and W % 64 == 0)
     assert rel_l2(wd.grad, wr.grad) < 3e-5
     # which kernel took it (the route is per calling thread, autograd's backward runs on another one: ask the C ABI directly)
     from faoctasr._lib import call, ptr, stream_ptr
@@ -631,6 +637,16 @@ def test_conv_transpose2d_bf16x3(fa, case):
         fa.ops.conv_precision = 0
     assert rel_l2(out, ref) < 3e-5
     assert rel_l2(xd.grad, xr.grad) < 3e-5
+    # weight gradient: the stride-2 row kernel of wgrad_x3.hip with x / dy swapped (route 15) where the shape allows it
+    wr = w.clone().requires_grad_(True)
+    F.conv_transpose2d(x, wr, None, stride=s, padding=p, output_padding=op).backward(cot)
+    from faoctasr._lib import call, ptr, stream_ptr
+    dwd = torch.zeros(C, M, k, k, device="cuda")
+    xk, ck = dev(x), dev(cot)                                 # (kept alive: the call only takes their addresses)
+    call("conv_transpose2d_wgrad", ptr(xk), ptr(ck), ptr(dwd), N, C, H, W, M, k, k, s, p, op, 0, 2, stream_ptr())
+    x3 = s == 2 and k in (3, 4) and p == 1 and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0 and ref.shape[-1] == 2 * W and ref.shape[-2] == 2 * H
+    assert (fa._lib.load().faoctasr_last_route() == 15) == x3, case
+    assert rel_l2(dwd, wr.grad) < 3e-5
 
 
 def test_input_pipeline_vs_oracle(fa, O):
