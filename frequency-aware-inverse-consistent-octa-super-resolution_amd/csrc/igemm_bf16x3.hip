@@ -23,6 +23,9 @@
 #include <cstdint>
 #include <type_traits>
 
+#ifndef SP_CDMA
+#define SP_CDMA 0                 // (experiment) 1: the CONSUMER waves issue the weight LDS-DMA of the next slab, one row per tap step
+#endif
 #ifndef SP_SPLIT_BELOW
 #define SP_SPLIT_BELOW 128        // grids with fewer blocks split the channel groups over the grid's z (atomics into a zeroed output).
                                   // Half a chip of blocks stays unsplit: the 256 -> 256 @32^2 layer alone is slower so (56 vs 46 us), the
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
             int nt = T - tb;
             nt = nt < TG ? nt : TG;
             d_rows = nt * 2;                                            // (tap, h) rows per plane
-            d_rows2 = (SP_ABLATE & 1) ? 0 : 2 * d_rows;
+            d_rows2 = ((SP_ABLATE & 1) || SP_CDMA) ? 0 : 2 * d_rows;
             d_r = wnu;
             d_src = wbase + ((long)grp * T + tb) * 2 * w_row;
             d_dst = smem + A_base + (abuf * 2) * a_bytes;
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
         load_patch(grp_l);                                               // patch 0
         advance_l();
         begin_A(g0, 0, 0);
+        if constexpr (SP_CDMA != 0) d_rows2 = (SP_ABLATE & 1) ? 0 : 2 * d_rows;      // slab 0 is the producers' in every variant
         rest_of_A();
         store_patch(0, no_hook);
         int in_flight = 0;
@@ -488,6 +492,34 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
     const unsigned b_lane = (unsigned)((lh * PH + (wn * NI) * SI) * PW + l31 * SI) * 16u;         // + tap*16, + ni*SI*PW*16
     const unsigned b_row = (unsigned)(SI * PW) * 16u;
 
+    // (SP_CDMA) weight rows of the NEXT slab, fetched by the consumers: wave wn takes rows wn, wn + 4, ...; one per tap step
+    const int wnu_c = __builtin_amdgcn_readfirstlane(wn);
+    const char* const wbase_c = reinterpret_cast<const char*>(wp + g.pack_off[ph] + (long)m0 * 8);
+    const long w_row_c = (long)g.Mpad * 16, w_plane_c = g.plane_stride * 2;
+    const unsigned lane16_c = (unsigned)lane * 16u;
+    const char* c_src = wbase_c;
+    char* c_dst = smem;
+    int c_r = 0, c_rows = 0, c_rows2 = 0;
+    auto c_begin = [&](int grp, int tgi, int abuf) {
+        const int tb2 = tgi * TG;
+        int nt2 = T - tb2;
+        nt2 = nt2 < TG ? nt2 : TG;
+        c_rows = nt2 * 2;
+        c_rows2 = 2 * c_rows;
+        c_r = wnu_c;
+        c_src = wbase_c + ((long)grp * T + tb2) * 2 * w_row_c;
+        c_dst = smem + A_base + (abuf * 2) * a_bytes;
+    };
+    auto c_next_row = [&]() {
+        if (c_r < c_rows2) {
+            const int plane = c_r >= c_rows ? 1 : 0;
+            const int rr = c_r - plane * c_rows;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c_src + plane * w_plane_c + rr * w_row_c + lane16_c),
+                                             (__attribute__((address_space(3))) void*)(c_dst + plane * a_bytes + rr * 1024), 16, 0, 0);
+            c_r += 4;
+        }
+    };
+
     long tile = blockIdx.x;
     asm volatile("s_barrier" ::: "memory");                             // first patch + first weight slab staged by the producers
     int slab = 0, pcount = 0;
@@ -541,15 +573,27 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                     });
                 };
                 SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 0);
+                if constexpr (SP_CDMA != 0) {
+                    c_rows2 = 0;
+                    const bool last_grp_c = grp + 1 >= g1;
+                    if (tgi + 1 < ntg) c_begin(grp, tgi + 1, abuf ^ 1);
+                    else if (!last_grp_c) c_begin(grp + 1, 0, abuf ^ 1);
+                    else if (has_next) c_begin(g0, 0, abuf ^ 1);
+                }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 rd_all(a0, b0, 0);
                 for (int tl = 0; tl < nt; tl += 2) {
+                    if constexpr (SP_CDMA != 0) c_next_row();
                     step(a0, b0, a1, b1, tl + 1);
                     if (tl + 1 >= nt) break;
+                    if constexpr (SP_CDMA != 0) c_next_row();
                     step(a1, b1, a0, b0, tl + 2);
                 }
+                if constexpr (SP_CDMA != 0)
+                    while (c_r < c_rows2) c_next_row();
                 SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // retire run-ahead reads before LDS is rewritten
+                if constexpr (SP_CDMA != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the rows this wave fetched have landed
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // retire run-ahead reads before LDS is rewritten
                 SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 2);
                 asm volatile("s_barrier" ::: "memory");                  // no vmcnt wait: the tile's output stores drain behind the next tile's MFMAs
                 SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 3);
