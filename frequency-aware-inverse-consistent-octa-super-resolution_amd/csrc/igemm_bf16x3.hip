@@ -23,6 +23,9 @@
 #include <cstdint>
 #include <type_traits>
 
+#ifndef SP_MIN_W
+#define SP_MIN_W 24               // narrower output maps are left to the fp32 narrow-map kernels (a 32-pixel tile row would be mostly empty)
+#endif
 #ifndef SP_CDMA
 #define SP_CDMA 0                 // (experiment) 1: the CONSUMER waves issue the weight LDS-DMA of the next slab, one row per tap step
 #endif
@@ -740,7 +743,7 @@ int split_geom_from(const IgemmGeom& f, SplitGeom& g) {
     const int ngroups = (g.C + 15) / 16;
     for (int p = 0; p < g.nphase; ++p) {
         const int T = g.t0[p + 1] - g.t0[p];
-        if (T == 0 || g.gw[p] < 24) return 0;
+        if (T == 0 || g.gw[p] < SP_MIN_W) return 0;
         int oy0 = 1 << 30, ox0 = 1 << 30, oy1 = -(1 << 30), ox1 = -(1 << 30);
         for (int t = g.t0[p]; t < g.t0[p + 1]; ++t) {
             const int oy = (f.taps[t] & 0xff) - 64, ox = ((f.taps[t] >> 8) & 0xff) - 64;
