@@ -23,6 +23,9 @@
 #include <cstdint>
 #include <type_traits>
 
+#ifndef SP_NCW8
+#define SP_NCW8 0                 // 1: large stride-1 layers on the 8-consumer-wave form (sp_launch_wide_block)
+#endif
 #ifndef SP_MIN_W
 #define SP_MIN_W 24               // narrower output maps are left to the fp32 narrow-map kernels (a 32-pixel tile row would be mostly empty)
 #endif
@@ -137,16 +140,18 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // QUAD: the producers stage the patch in 4-pixel pieces (round 3): a thread's item is (channel half, patch row, 4 consecutive pixels
 // starting at a 16-byte aligned image column) = 8 x buffer_load_dwordx4, one per channel, instead of 32 dword loads; the <= 3 + 3
 // columns of a patch row left and right of the aligned run stay single-pixel items.  Host-side conditions: sp_quad_ok().
-template <int NI, int SI, bool QUAD>
-__global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
+// NCW: consumer waves (4, or 8 = two per SIMD: a 16-row pixel tile per block at the 4-wave form's registers per wave -- the weight slab,
+// 46 % of the block's memory traffic, then feeds twice the MFMAs; three waves per SIMD leave 168 registers each).
+template <int NI, int SI, bool QUAD, int NCW = 4>
+__global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
                                                            const int ksplit, const int wide) {
-    constexpr int MI = 2, TH = 4 * NI, NT = 256, NPI = SP_NPI;
+    constexpr int MI = 2, TH = NCW * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const bool producer = SP_PROD_FIRST ? wave < 4 : wave >= 4;
-    const int wn = wave & 3, stid = tid & 255;
+    const bool producer = (SP_PROD_FIRST && NCW == 4) ? wave < 4 : wave >= NCW;
+    const int wn = NCW == 4 ? wave & 3 : (wave >= NCW ? wave - NCW : wave), stid = tid & 255;      // consumer index 0 .. NCW-1 / producer index 0 .. 3
     const int ph = blockIdx.z / ksplit, ks = blockIdx.z - ph * ksplit;
     const int GH = g.gh[ph], GW = g.gw[ph];
     const int tiles_x = (GW + 31) >> 5, tiles_y = (GH + TH - 1) / TH;
@@ -300,38 +305,38 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                         // hi = bf16(x) of two CHANNELS of a pixel is one v_cvt_pk_bf16_f32 (the LDS order); x - float(hi) of two PIXELS
                         // of a channel is one v_pk_add_f32 on the register pair the dwordx4 load left them in: 2.5 instructions per
                         // element and no moves (pairing channels for the subtraction cost two v_mov per pair)
-                        unsigned hd[4][4], ld[4][4];                     // [pixel][channel pair]
-                        f32x2s lo[8][2];                                 // [channel][pixel pair]
+                        // one PIXEL PAIR at a time (32 temporaries instead of 64: the 8-consumer-wave form has 168 registers per wave)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                        for (int kp = 0; kp < 2; ++kp) {
+                            unsigned hd[2][4], ld[2][4];                 // [pixel of the pair][channel pair]
+                            f32x2s lo[8];                                // [channel]
 #pragma unroll
-                            for (int c2 = 0; c2 < 4; ++c2)
-                                hd[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{qv[i][2 * c2][k], qv[i][2 * c2 + 1][k]}, bf16x2s));
-                        hook();
+                            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
+                                for (int c2 = 0; c2 < 4; ++c2)
+                                    hd[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{qv[i][2 * c2][2 * kp + k], qv[i][2 * c2 + 1][2 * kp + k]}, bf16x2s));
+                            hook();
 #pragma unroll
-                            for (int kp = 0; kp < 2; ++kp) {
-                                const unsigned d0 = hd[2 * kp][c >> 1], d1 = hd[2 * kp + 1][c >> 1];
+                            for (int c = 0; c < 8; ++c) {
+                                const unsigned d0 = hd[0][c >> 1], d1 = hd[1][c >> 1];
                                 const f32x2s hf = {__builtin_bit_cast(float, (c & 1) ? d0 & 0xffff0000u : d0 << 16),
                                                    __builtin_bit_cast(float, (c & 1) ? d1 & 0xffff0000u : d1 << 16)};
-                                lo[c][kp] = f32x2s{qv[i][c][2 * kp], qv[i][c][2 * kp + 1]} - hf;
+                                lo[c] = f32x2s{qv[i][c][2 * kp], qv[i][c][2 * kp + 1]} - hf;
+                                if ((c & 3) == 3) hook();
                             }
-                            if (c & 1) hook();
-                        }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                            for (int c2 = 0; c2 < 4; ++c2)
-                                ld[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{lo[2 * c2][k >> 1][k & 1], lo[2 * c2 + 1][k >> 1][k & 1]}, bf16x2s));
-                        hook();
+                                for (int c2 = 0; c2 < 4; ++c2)
+                                    ld[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{lo[2 * c2][k], lo[2 * c2 + 1][k]}, bf16x2s));
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (qok && (unsigned)(px0 + k) < (unsigned)PW) {        // not: a covering piece's columns beyond the patch row
-                                *reinterpret_cast<u32x4s*>(hi_p + (q_slot[i] + k) * 16) = u32x4s{hd[k][0], hd[k][1], hd[k][2], hd[k][3]};
-                                *reinterpret_cast<u32x4s*>(lo_p + (q_slot[i] + k) * 16) = u32x4s{ld[k][0], ld[k][1], ld[k][2], ld[k][3]};
+                            for (int k = 0; k < 2; ++k) {
+                                if (qok && (unsigned)(px0 + 2 * kp + k) < (unsigned)PW) {       // not: a covering piece's columns beyond the patch row
+                                    *reinterpret_cast<u32x4s*>(hi_p + (q_slot[i] + 2 * kp + k) * 16) = u32x4s{hd[k][0], hd[k][1], hd[k][2], hd[k][3]};
+                                    *reinterpret_cast<u32x4s*>(lo_p + (q_slot[i] + 2 * kp + k) * 16) = u32x4s{ld[k][0], ld[k][1], ld[k][2], ld[k][3]};
+                                }
+                                hook();
                             }
-                            hook();
                         }
                     }
                 }
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                 const bool more_patch = !last_grp || has_next;
                 for (int tgi = 0; tgi < ntg; ++tgi, ++slab) {
                     const int abuf = slab & 1;
-                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 3072, slab, 0);
+                    SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 3072, slab, 0);
                     in_flight = 0;
                     const bool swap_patch = tgi == ntg - 1 && more_patch;
                     d_rows2 = 0;
@@ -458,17 +463,17 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                     else if (!last_grp) begin_A(grp + 1, 0, abuf ^ 1);
                     else if (has_next) begin_A(g0, 0, abuf ^ 1);
                     if (swap_patch) store_patch(pbuf ^ 1, next_row);     // patch p + 1 (loaded a slab or a channel group ago), DMA in between
-                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 0);
+                    SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 1024, slab, 0);
                     rest_of_A();
-                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 1);
+                    SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 1024, slab, 1);
                     if (swap_patch && valid_l) {
                         load_patch(grp_l);                               // patch p + 2
                         advance_l();
                         in_flight = npl_full;
                     }
-                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 2);
+                    SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 1024, slab, 2);
                     barrier_keep(in_flight);                             // LDS-DMA landed, patch visible, consumers done
-                    SPTRACE(tid == (SP_PROD_FIRST ? 0 : 256), 1024, slab, 3);
+                    SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 1024, slab, 3);
                 }
             }
             if (!has_next) break;
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 };
-                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 0);
+                SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 2048, slab, 0);
                 if constexpr (SP_CDMA != 0) {
                     c_rows2 = 0;
                     const bool last_grp_c = grp + 1 >= g1;
@@ -594,12 +599,12 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
                 }
                 if constexpr (SP_CDMA != 0)
                     while (c_r < c_rows2) c_next_row();
-                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 1);
+                SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 2048, slab, 1);
                 if constexpr (SP_CDMA != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the rows this wave fetched have landed
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // retire run-ahead reads before LDS is rewritten
-                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 2);
+                SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 2048, slab, 2);
                 asm volatile("s_barrier" ::: "memory");                  // no vmcnt wait: the tile's output stores drain behind the next tile's MFMAs
-                SPTRACE(tid == (SP_PROD_FIRST ? 256 : 0), 2048, slab, 3);
+                SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 2048, slab, 3);
             }
         }
         // ---- epilogue of this tile; the producers are already staging the next tile
@@ -710,12 +715,12 @@ __global__ __launch_bounds__(512) void igemm_bf16x3_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------
 constexpr size_t SP_LDS_MAX = 156 * 1024;
 
-static size_t sp_lds(const SplitGeom& g, int NI, int SI, bool staging = true) {
+static size_t sp_lds(const SplitGeom& g, int NI, int SI, bool staging = true, int ncw = 4) {      // NI: rows per tile / 4
     const int TH = 4 * NI;
     size_t best = 0;
     for (int p = 0; p < g.nphase; ++p) {
         const int PH = (TH - 1) * SI + g.span_y[p] + 1, PW = 31 * SI + g.span_x[p] + 1;
-        const size_t b = 4 * (size_t)g.tg[p] * 2048 + 4 * (size_t)(2 * PH * PW) * 16 + (staging ? 16384 : 0) + 2048;      // weights, patch, output staging
+        const size_t b = 4 * (size_t)g.tg[p] * 2048 + 4 * (size_t)(2 * PH * PW) * 16 + (staging ? 4096 * (size_t)ncw : 0) + 2048;      // weights, patch, output staging
         best = b > best ? b : best;
     }
     return best;
@@ -853,8 +858,39 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     return check_launch("igemm_bf16x3");
 }
 
+// Eight consumer waves (two per SIMD) + four producers: a 16-row x 32-pixel tile per block (512 pixels per 64 output channels).  Taken
+// for stride-1 single-phase layers whose 512-pixel tiles still give every CU at least two tiles, when the 4-pixel patch items and the
+// 16-byte epilogue apply; the tap group shrinks to <= 5 taps so that the two weight buffers leave room for the larger patch.
+static int sp_launch_wide_block(const float* x, const float* wp, const float* bias, float* y, SplitGeom g, hipStream_t s) {
+    if (!SP_NCW8 || g.SI != 1 || g.nphase != 1) return 0;
+    constexpr int TH = 16;
+    const long tiles = (long)g.N * ((g.gw[0] + 31) / 32) * ((g.gh[0] + TH - 1) / TH);
+    const int gy = (g.M + SP_MT - 1) / SP_MT;
+    if (tiles * gy < 512 || tiles >= (1L << 31) || (long)g.M * g.OH * g.OW >= (1L << 30)) return 0;
+    const int T = g.t0[1] - g.t0[0];
+    int tg = g.tg[0];
+    if (tg > 5) tg = T % 5 == 0 ? 5 : (T % 4 == 0 ? 4 : (T % 3 == 0 ? 3 : 5));
+    g.tg[0] = tg;
+    const size_t lds = sp_lds(g, 4, 1, true, 8);
+    if (lds > SP_LDS_MAX || !sp_quad_ok(g, 4, x)) return 0;
+    const bool wide_ok = SP_WIDE && g.SO == 1 && (g.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (g.gw[0] & 3) == 0 && (g.px[0] & 3) == 0;
+    if (!wide_ok) return 0;
+    long nbx = 256 / gy;
+    nbx = nbx < 1 ? 1 : nbx;
+    if (nbx > tiles) nbx = tiles;
+    auto k = igemm_bf16x3_kernel<2, 1, true, 8>;
+    lds_optin((const void*)k, lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)nbx, gy, 1), dim3(768), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, 1, 1);
+    const int rc = check_launch("igemm_bf16x3 (8 consumer waves)");
+    return rc == FAOCTASR_OK ? 1 : rc;
+}
+
 int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s) {
     g.act = act; g.slope = slope;
+    {
+        const int rc = sp_launch_wide_block(x, wp, bias, y, g, s);
+        if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
+    }
     if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s);
     return sp_launch<1>(x, wp, bias, y, g, s);
 }
