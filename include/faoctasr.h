@@ -77,8 +77,10 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx,
                           float* wpack, int wpack_state, int precision, faoctasr_stream_t stream);
 /* aten::convolution_backward, weight gradient.  dw[M,C,KH,KW] is overwritten, or added to
  * when accumulate != 0 (the gradient arena is zeroed once per step instead).  precision as above: 2 = bf16x3 (hi/lo-split dY
- * and X on v_mfma_f32_32x32x16_bf16) for the stride-1 3x3 layers with C, M multiples of 64 and W a multiple of 32; other shapes
- * silently use the fp32 kernels.                                                            */
+ * and X on v_mfma_f32_32x32x16_bf16) for the stride-1 3x3 (pad 1) and 7x7 (pad 3, reflection or zero padding) layers and the
+ * stride-2 3x3 / 4x4 (pad 1) layers, with C, M multiples of 64, an output width that is a multiple of 32 and an even output
+ * height (the transposed convolution's weight gradient takes the stride-2 form with x and dy swapped); other shapes silently
+ * use the fp32 kernels.  faoctasr_last_route() tells which (15 = bf16x3).                    */
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw,
                           int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                           int reflect, int accumulate, int precision, faoctasr_stream_t stream);
