@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE config 2: 8)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "f16x2"],
                     help="conv contraction: exact fp32 MFMA (default, the headline) or bf16x3 split operands on the bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

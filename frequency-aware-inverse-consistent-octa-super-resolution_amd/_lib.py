@@ -19,6 +19,9 @@ _SIG = {
     "conv_wpack_floats": (_L, "iiiiiiii"),
     "conv_pack_job": (_L, "p l i pp iiiiiiiii i i i"),
     "conv_pack_run": (_I, "p i l p"),
+    "conv_pack_scales": (_I, "p i p"),
+    "absmax_bits": (_I, "p l p p"),
+    "conv_set_scales": (_I, "pp"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
     "conv2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),

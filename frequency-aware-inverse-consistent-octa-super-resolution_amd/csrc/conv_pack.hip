@@ -26,7 +26,17 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const char* __rest
     if (lb >= J.blocks) return;                    // cannot happen for a table built by faoctasr_conv_pack_job; keeps a bad table harmless
     if (J.type == PACK_PATCH) patch_pack_block(J.w, J.wp, J.g.patch, lb, J.blocks);
     else if (J.type == PACK_WINO) wino_pack_block(J.w, J.wp, J.g.wino, lb, J.blocks);
-    else if (J.type == PACK_SPLIT) split_pack_block(J.w, reinterpret_cast<__bf16*>(J.wp), J.g.split, lb, J.blocks);
+    else if (J.type == PACK_SPLIT) {
+        if (J.g.split.f16) split_pack_block<true>(J.w, reinterpret_cast<unsigned short*>(J.wp), J.g.split, lb, J.blocks);
+        else split_pack_block<false>(J.w, reinterpret_cast<unsigned short*>(J.wp), J.g.split, lb, J.blocks);
+    }
+}
+
+// f16x2 images: the weights' absmax slots, one block per job, before the images are packed (pack_bodies.h, split16.h)
+__global__ __launch_bounds__(256) void conv_pack_absmax_kernel(const char* __restrict__ jobs, int njobs) {
+    __shared__ unsigned red[4];
+    const PackJob& J = *reinterpret_cast<const PackJob*>(jobs + (size_t)blockIdx.x * PACK_JOB_BYTES);
+    if (J.type == PACK_SPLIT && J.g.split.f16) split_absmax_block(J.w, J.wp, J.g.split, red);
 }
 
 }  // namespace faoctasr
@@ -34,6 +44,13 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const char* __rest
 using namespace faoctasr;
 
 extern "C" {
+
+int faoctasr_conv_pack_scales(const void* jobs_dev, int njobs, faoctasr_stream_t stream) {
+    if (njobs == 0) return FAOCTASR_OK;
+    if (!jobs_dev || njobs < 0) return fail(FAOCTASR_EINVAL, "conv_pack_scales: bad job table");
+    hipLaunchKernelGGL(conv_pack_absmax_kernel, dim3((unsigned)njobs), dim3(256), 0, (hipStream_t)stream, (const char*)jobs_dev, njobs);
+    return check_launch("conv_pack_absmax");
+}
 
 int faoctasr_conv_pack_run(const void* jobs_dev, int njobs, long nblocks, faoctasr_stream_t stream) {
     if (njobs == 0 || nblocks == 0) return FAOCTASR_OK;

@@ -449,19 +449,28 @@ static int launch_wgrad(const float* x, const float* dy, float* dw, IgemmGeom& g
 
 static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || !b || !c; }
 
+// the absmax slots faoctasr_conv_set_scales left for this thread's next convolution-type call: taken (and cleared) by that call
+thread_local const unsigned* g_scale_a = nullptr;
+thread_local const unsigned* g_scale_b = nullptr;
+static const unsigned* take_scale_a() {
+    const unsigned* a = g_scale_a;
+    g_scale_a = g_scale_b = nullptr;
+    return a;
+}
+
 // wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
 // precision: 0 = f32 MFMA, Winograd F(2x2,3x3) for the dense stride-1 3x3 gathers and direct implicit GEMM elsewhere;
 //            1 = f32 MFMA, direct implicit GEMM only; 2 = bf16x3 split operands on the bf16 MFMA where the layer shape allows it
 // sink: record the weight-packing job this call would launch (wpack_state 1) and launch nothing (faoctasr_conv_pack_job);
 // sink->blocks stays 0 when the call's route uses no packed image.
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
-                      int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr) {
+                      int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr, const unsigned* slot_a = nullptr) {
     // FAOCTASR_CONV_NO_SPLIT_K: a reproducible result (one block owns the whole reduction of an output element) for this call
     struct Scope { int prev; Scope(int v) : prev(g_no_split_k) { g_no_split_k = v; } ~Scope() { g_no_split_k = prev; } } scope((precision & FAOCTASR_CONV_NO_SPLIT_K) ? 1 : 0);
     precision &= 0xff;
-    if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
-    if (wpack && wpack_state && precision == 2) {
-        const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink);
+    if (precision < 0 || precision > 3) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3, 3 = f16x2)", precision);
+    if (wpack && wpack_state && precision >= 2) {
+        const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, sink, precision == 3, slot_a);
         if (rc != 0 && sink) { sink->blocks = pack_job_blocks(sink->total / (8L * sink->g.split.Mpad)); return FAOCTASR_OK; }
         if (rc != 0) { set_route(ROUTE_BF16X3); return rc < 0 ? rc : FAOCTASR_OK; }
     }
@@ -496,7 +505,7 @@ static long wpack_floats(IgemmGeom& g, int precision) {
     PatchGeom pg;
     if (patch_geom_from(g, pg)) return 0;
     long n = patch_pack_floats(pg);
-    if (precision == 2) {
+    if (precision >= 2) {
         const long m = split_pack_floats_for(g);
         n = m > n ? m : n;
     }
@@ -573,9 +582,16 @@ long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const flo
     return job.blocks;
 }
 
+int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b) {
+    g_scale_a = slot_a;
+    g_scale_b = slot_b;
+    return FAOCTASR_OK;
+}
+
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,
                         int KH, int KW, int stride, int pad, int reflect, int act, float slope, float* wpack, int wpack_state,
                         int precision, faoctasr_stream_t stream) {
+    const unsigned* const slot_a = take_scale_a();
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv2d_fwd: null pointer");
     if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
@@ -588,11 +604,12 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
 }
 
 int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW,
                           int stride, int pad, float* wpack, int wpack_state, int precision, faoctasr_stream_t stream) {
+    const unsigned* const slot_a = take_scale_a();
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
@@ -604,14 +621,17 @@ int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int
     // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
     int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
 }
 
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
                           int stride, int pad, int reflect, int accumulate, int precision, faoctasr_stream_t stream) {
+    const unsigned *const slot_x = g_scale_a, *const slot_dy = g_scale_b;
+    g_scale_a = g_scale_b = nullptr;
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
     precision &= 0xff;             // the weight gradients have no split-K policy to switch: they always accumulate with atomics
-    if (precision < 0 || precision > 2) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3)", precision);
+    if (precision < 0 || precision > 3) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3, 3 = f16x2)", precision);
+    if (precision == 3 && (!slot_x || !slot_dy)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: precision 3 (f16x2) needs both absmax slots: faoctasr_conv_set_scales");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: bad shape");
     if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
@@ -629,9 +649,9 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
     if (OW >= 24) {      // wide maps: LDS-patch weight gradient (atomics into dw, zeroed here unless accumulating)
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
-        if (precision == 2) {      // split-precision operands on the bf16 MFMA where the layer shape allows it
+        if (precision >= 2) {      // split-precision operands on the 16-bit MFMA where the layer shape allows it
             rc = launch_wgrad_x3(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, precision == 3, slot_x, slot_dy);
             if (rc != 0) { set_route(ROUTE_WGRAD_X3); return rc < 0 ? rc : FAOCTASR_OK; }
         }
         rc = launch_wgrad_s1(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW,
@@ -650,6 +670,7 @@ int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int
 int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW,
                                   int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope, float* wpack,
                                   int wpack_state, int precision, faoctasr_stream_t stream) {
+    const unsigned* const slot_a = take_scale_a();
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: bad shape");
@@ -657,24 +678,29 @@ int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* b
     // w[c][m][t]: m stride = KK, c stride = M*KK
     int rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, (long)KH * KW, (long)M * KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
 }
 
 int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH,
                                     int KW, int stride, int pad, int out_pad, float* wpack, int wpack_state, int precision,
                                     faoctasr_stream_t stream) {
+    const unsigned* const slot_a = take_scale_a();
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_dgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;
     // dx[n][c][iy][ix] = sum_{m,t} dy[n][m][iy*s-p+kh][..] * w[c][m][t]: forward-mode gather over dy
     int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
 }
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,
                                     int KW, int stride, int pad, int out_pad, int accumulate, int precision, faoctasr_stream_t stream) {
+    const unsigned *const slot_x = g_scale_a, *const slot_dy = g_scale_b;
+    g_scale_a = g_scale_b = nullptr;
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: null pointer");
+    precision &= 0xff;
+    if (precision == 3 && (!slot_x || !slot_dy)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: precision 3 (f16x2) needs both absmax slots: faoctasr_conv_set_scales");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;
     // dw[c][m][t] = sum x[n][c][iy][ix] * dy[n][m][iy*s-p+kh][..]: conv-wgrad with source dy (M channels) and "dY" = x
@@ -683,8 +709,9 @@ int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, 
     if (IW >= 24) {
         if (!accumulate && hipMemsetAsync(dw, 0, sizeof(float) * (size_t)M * C * KH * KW, (hipStream_t)stream) != hipSuccess)
             return fail(FAOCTASR_EHIP, "memset dw failed");
-        if (precision == 2) {      // split-precision operands on the bf16 MFMA (stride-2 row kernel with x / dy swapped)
-            rc = launch_wgrad_x3(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW, (hipStream_t)stream);
+        if (precision >= 2) {      // split-precision operands on the 16-bit MFMA (stride-2 row kernel with x / dy swapped)
+            rc = launch_wgrad_x3(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW, (hipStream_t)stream,
+                                 precision == 3, slot_dy, slot_x);
             if (rc != 0) { set_route(ROUTE_WGRAD_X3); return rc < 0 ? rc : FAOCTASR_OK; }
         }
         rc = launch_wgrad_s1(dy, x, dw, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW,

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "igemm_geom.h"
 #include "pack_bodies.h"
+#include "split16.h"
 #include <cstdlib>
 #include <cstdint>
 #include <type_traits>
@@ -125,8 +126,13 @@ __device__ __forceinline__ void wait_keep_next(bf16x8 (&a)[MI][2], bf16x8 (&b)[N
 // ---------------------------------------------------------------------------------------------------------------
 // weight packing: fp32 W (arbitrary m / c strides, tap list) -> two bf16 planes in the LDS image order
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom g) {
-    split_pack_block(w, wp, g, blockIdx.x, gridDim.x);
+template <bool F16>
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const SplitGeom g) {
+    split_pack_block<F16>(w, wp, g, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void split_absmax_kernel(const float* __restrict__ w, float* __restrict__ wp, const SplitGeom g) {
+    __shared__ unsigned red[4];
+    split_absmax_block(w, wp, g, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -142,10 +148,13 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // columns of a patch row left and right of the aligned run stay single-pixel items.  Host-side conditions: sp_quad_ok().
 // NCW: consumer waves (4, or 8 = two per SIMD: a 16-row pixel tile per block at the 4-wave form's registers per wave -- the weight slab,
 // 46 % of the block's memory traffic, then feeds twice the MFMAs; three waves per SIMD leave 168 registers each).
-template <int NI, int SI, bool QUAD, int NCW = 4>
+// F16: f16x2 operands (split16.h): the producers stage x * s(x_slot), the packed image holds w * s(w_slot), the epilogue divides
+// the two scales out of the accumulators; everything else is the bf16x3 kernel.
+template <int NI, int SI, bool QUAD, int NCW = 4, bool F16 = false>
 __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
-                                                           const int ksplit, const int wide) {
+                                                           const int ksplit, const int wide, const unsigned* __restrict__ x_slot,
+                                                           const unsigned* __restrict__ w_slot) {
     constexpr int MI = 2, TH = NCW * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,6 +199,8 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         constexpr unsigned OOB = 0x80000000u;
         const unsigned cstep = 4u * (unsigned)chw;
         const float* xin = x;
+        float sx = 1.f;                                                  // f16x2: the activation tensor's scale (wave-uniform)
+        if constexpr (F16) sx = f16x2_scale(*x_slot);
         // ---- single-pixel items (all of the patch when !QUAD)
         constexpr int NSI = QUAD ? 2 : NPI;
         unsigned poff[NSI];
@@ -302,6 +313,10 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                     if (NT * i < nqi) {                                  // block-uniform (hook() issues a DMA: every lane must be there);
                         const bool qok = q_pos[i] >= 0;                  // lanes without an item compute on zeros and store nothing
                         const int px0 = ((q_pos[i] >> 8) & 0xff) - 4;
+                        if constexpr (F16) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) qv[i][j] *= sx;
+                        }
                         // hi = bf16(x) of two CHANNELS of a pixel is one v_cvt_pk_bf16_f32 (the LDS order); x - float(hi) of two PIXELS
                         // of a channel is one v_pk_add_f32 on the register pair the dwordx4 load left them in: 2.5 instructions per
                         // element and no moves (pairing channels for the subtraction cost two v_mov per pair)
@@ -314,13 +329,12 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
                                 for (int c2 = 0; c2 < 4; ++c2)
-                                    hd[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{qv[i][2 * c2][2 * kp + k], qv[i][2 * c2 + 1][2 * kp + k]}, bf16x2s));
+                                    hd[k][c2] = cvt_pair<F16>(qv[i][2 * c2][2 * kp + k], qv[i][2 * c2 + 1][2 * kp + k]);
                             hook();
 #pragma unroll
                             for (int c = 0; c < 8; ++c) {
                                 const unsigned d0 = hd[0][c >> 1], d1 = hd[1][c >> 1];
-                                const f32x2s hf = {__builtin_bit_cast(float, (c & 1) ? d0 & 0xffff0000u : d0 << 16),
-                                                   __builtin_bit_cast(float, (c & 1) ? d1 & 0xffff0000u : d1 << 16)};
+                                const f32x2s hf = {(c & 1) ? half_hi_f32<F16>(d0) : half_lo_f32<F16>(d0), (c & 1) ? half_hi_f32<F16>(d1) : half_lo_f32<F16>(d1)};
                                 lo[c] = f32x2s{qv[i][c][2 * kp], qv[i][c][2 * kp + 1]} - hf;
                                 if ((c & 3) == 3) hook();
                             }
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                             for (int k = 0; k < 2; ++k)
 #pragma unroll
                                 for (int c2 = 0; c2 < 4; ++c2)
-                                    ld[k][c2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{lo[2 * c2][k], lo[2 * c2 + 1][k]}, bf16x2s));
+                                    ld[k][c2] = cvt_pair<F16>(lo[2 * c2][k], lo[2 * c2 + 1][k]);
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 if (qok && (unsigned)(px0 + 2 * kp + k) < (unsigned)PW) {       // not: a covering piece's columns beyond the patch row
@@ -344,16 +358,16 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
 #pragma unroll
             for (int i = 0; i < NSI; ++i) {
                 if (s_pos[i] >= 0) {
-                    bf16x8 hv, lv;
+                    u32x4s hv, lv;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float v = pv[i][j];
-                        const __bf16 hb = (__bf16)v;
-                        hv[j] = hb;
-                        lv[j] = (__bf16)(v - (float)hb);
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned h, l;
+                        split_pair<F16>(pv[i][2 * j] * sx, pv[i][2 * j + 1] * sx, h, l);
+                        hv[j] = h;
+                        lv[j] = l;
                     }
-                    *reinterpret_cast<bf16x8*>(hi_p + s_slot[i] * 16) = hv;
-                    *reinterpret_cast<bf16x8*>(lo_p + s_slot[i] * 16) = lv;
+                    *reinterpret_cast<u32x4s*>(hi_p + s_slot[i] * 16) = hv;
+                    *reinterpret_cast<u32x4s*>(lo_p + s_slot[i] * 16) = lv;
                 }
             }
         };
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                             if constexpr (j == 0) acc[0][0][0] += (float)a[0][0][0] + (float)a[MI - 1][1][0] + (float)b[0][0][0] + (float)b[NI - 1][1][0];
                         } else {
                             // term 0: lo*hi, 1: hi*lo, 2: hi*hi
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][term == 0 ? 1 : 0], b[ni][term == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+                            mfma16<F16>(a[mi][term == 0 ? 1 : 0], b[ni][term == 1 ? 1 : 0], acc[mi][ni]);
                         }
                         if constexpr (j < 2 * MI) ds_read_v8(an[j / 2][j % 2], (j % 2 ? Al : Ah) + ao + (j / 2) * 512u);
                         else if constexpr (j < 2 * (MI + NI)) ds_read_v8(bn[(j - 2 * MI) / 2][(j - 2 * MI) % 2], ((j - 2 * MI) % 2 ? Pl : Ph) + bo + ((j - 2 * MI) / 2) * b_row);
@@ -612,6 +626,15 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             int cn, cty, ctx;
             tile_coords(tile, cn, cty, ctx);
             const int mrow0 = m0 + 4 * lh;
+            if constexpr (F16) {                                         // the operands were x * s_x and w * s_w
+                const float inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*w_slot);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] *= inv;
+            }
             if (bias && ks == 0) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
@@ -736,8 +759,13 @@ static bool sp_fits(const SplitGeom& g, int NI, int SI) {
 }
 
 // 1 when the layer can run on the split kernel (decided by the layer shape only)
-int split_geom_from(const IgemmGeom& f, SplitGeom& g) {
+int split_geom_from(const IgemmGeom& f, SplitGeom& g, int f16 = 0) {
     g = SplitGeom{};
+    g.f16 = f16 ? 1 : 0;
+    {
+        const long a = (long)f.M * f.wsm, b = (long)f.C * f.wsc;
+        g.w_elems = a > b ? a : b;
+    }
     g.N = f.N; g.C = f.C; g.IH = f.IH; g.IW = f.IW; g.M = f.M; g.OH = f.OH; g.OW = f.OW; g.SI = f.SI; g.SO = f.SO;
     g.nphase = f.nphase; g.reflect = f.reflect; g.act = f.act; g.slope = f.slope; g.wsm = f.wsm; g.wsc = f.wsc;
     if (g.C < 16 || (g.SI != 1 && g.SI != 2)) return 0;
@@ -806,12 +834,17 @@ long split_pack_floats(const SplitGeom& g) { return g.plane_stride + 512; }   //
 int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t s) {
     const long total = g.pack_off[4];
     if (total <= 0) return FAOCTASR_OK;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<__bf16*>(wp), g);
+    if (g.f16) {
+        hipLaunchKernelGGL(split_absmax_kernel, dim3(1), dim3(256), 0, s, w, wp, g);
+        hipLaunchKernelGGL(split_pack_kernel<true>, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), g);
+    } else {
+        hipLaunchKernelGGL(split_pack_kernel<false>, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), g);
+    }
     return check_launch("split_pack");
 }
 
 template <int NI>
-static int sp_launch(const float* x, const float* wp, const float* bias, float* y, const SplitGeom& g, hipStream_t s) {
+static int sp_launch(const float* x, const float* wp, const float* bias, float* y, const SplitGeom& g, hipStream_t s, const unsigned* x_slot) {
     constexpr int TH = 4 * NI;
     long mx = 0;
     for (int p = 0; p < g.nphase; ++p) {
@@ -844,25 +877,34 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     bool wide_ok = SP_WIDE && staging && g.SO == 1 && g.nphase == 1 && (g.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && ksplit == 1;
     for (int p = 0; p < g.nphase; ++p) wide_ok = wide_ok && (g.gw[p] & 3) == 0 && (g.px[p] & 3) == 0;
     const int wide = wide_ok ? 1 : 0;
+    const unsigned* w_slot = reinterpret_cast<const unsigned*>(wp) + split_scale_slot(g);
     auto go = [&](auto k) {
         lds_optin((const void*)k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit, wide);
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit, wide, x_slot, w_slot);
     };
-    if (g.SI == 1) {
+    if (g.f16) {
+        if (g.SI == 1) {
+            if (quad) go(igemm_bf16x3_kernel<NI, 1, true, 4, true>);
+            else go(igemm_bf16x3_kernel<NI, 1, false, 4, true>);
+        } else {
+            if (quad) go(igemm_bf16x3_kernel<NI, 2, true, 4, true>);
+            else go(igemm_bf16x3_kernel<NI, 2, false, 4, true>);
+        }
+    } else if (g.SI == 1) {
         if (quad) go(igemm_bf16x3_kernel<NI, 1, true>);
         else go(igemm_bf16x3_kernel<NI, 1, false>);
     } else {
         if (quad) go(igemm_bf16x3_kernel<NI, 2, true>);
         else go(igemm_bf16x3_kernel<NI, 2, false>);
     }
-    return check_launch("igemm_bf16x3");
+    return check_launch(g.f16 ? "igemm_f16x2" : "igemm_bf16x3");
 }
 
 // Eight consumer waves (two per SIMD) + four producers: a 16-row x 32-pixel tile per block (512 pixels per 64 output channels).  Taken
 // for stride-1 single-phase layers whose 512-pixel tiles still give every CU at least two tiles, when the 4-pixel patch items and the
 // 16-byte epilogue apply; the tap group shrinks to <= 5 taps so that the two weight buffers leave room for the larger patch.
 static int sp_launch_wide_block(const float* x, const float* wp, const float* bias, float* y, SplitGeom g, hipStream_t s) {
-    if (!SP_NCW8 || g.SI != 1 || g.nphase != 1) return 0;
+    if (!SP_NCW8 || g.f16 || g.SI != 1 || g.nphase != 1) return 0;
     constexpr int TH = 16;
     const long tiles = (long)g.N * ((g.gw[0] + 31) / 32) * ((g.gh[0] + TH - 1) / TH);
     const int gy = (g.M + SP_MT - 1) / SP_MT;
@@ -880,25 +922,28 @@ static int sp_launch_wide_block(const float* x, const float* wp, const float* bi
     if (nbx > tiles) nbx = tiles;
     auto k = igemm_bf16x3_kernel<2, 1, true, 8>;
     lds_optin((const void*)k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)nbx, gy, 1), dim3(768), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, 1, 1);
+    hipLaunchKernelGGL(k, dim3((unsigned)nbx, gy, 1), dim3(768), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, 1, 1,
+                       (const unsigned*)nullptr, (const unsigned*)nullptr);
     const int rc = check_launch("igemm_bf16x3 (8 consumer waves)");
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 
-int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s) {
+int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s,
+                 const unsigned* x_slot) {
     g.act = act; g.slope = slope;
     {
         const int rc = sp_launch_wide_block(x, wp, bias, y, g, s);
         if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
     }
-    if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s);
-    return sp_launch<1>(x, wp, bias, y, g, s);
+    if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s, x_slot);
+    return sp_launch<1>(x, wp, bias, y, g, s, x_slot);
 }
 
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s, PackJob* sink) {
+              int wpack_state, hipStream_t s, PackJob* sink, int f16, const unsigned* x_slot) {
     SplitGeom g;
-    if (!split_geom_from(f, g)) return 0;
+    if (!split_geom_from(f, g, f16)) return 0;
+    if (f16 && !sink && !x_slot) return fail(FAOCTASR_EINVAL, "precision 3 (f16x2) needs the gathered tensor's absmax slot: faoctasr_conv_set_scales");
     if (sink) {
         sink->type = PACK_SPLIT; sink->w = w; sink->wp = wpack; sink->g.split = g; sink->total = g.pack_off[4];
         return 1;
@@ -907,7 +952,7 @@ int split_try(const IgemmGeom& f, const float* x, const float* w, const float* b
         const int rc = launch_split_pack(w, wpack, g, s);
         if (rc) return rc;
     }
-    const int rc = launch_split(x, wpack, bias, y, g, act, slope, s);
+    const int rc = launch_split(x, wpack, bias, y, g, act, slope, s, x_slot);
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 

@@ -53,8 +53,12 @@ struct SplitGeom {
     int tg[4];                     // taps per tap group
     long pack_off[5];              // bf16 element offset of each phase inside a plane
     long plane_stride;             // bf16 elements between the hi and the lo plane
+    int f16;                       // 1: f16x2 planes of w * s (split16.h); the weights' absmax slot is the image's last word
+    long w_elems;                  // extent of the weight tensor (its absmax is taken over all of it)
     int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
 };
+// float index of the weights' absmax slot inside a split-precision packed image (split_pack_floats() - 1)
+inline __host__ __device__ long split_scale_slot(const SplitGeom& g) { return g.plane_stride + 511; }
 
 // One weight-packing job of a batched launch (conv_pack.hip; include/faoctasr.h FAOCTASR_PACK_JOB_BYTES).  A job is what a
 // wpack_state == 1 call would have launched by itself: the same geometry, the same element order.
@@ -84,17 +88,23 @@ int launch_narrow(const float* x, const float* wp, const float* bias, float* y, 
 int launch_wgrad_patch(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                        int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 // bf16x3 split-precision weight gradient of the stride-1 3x3 layers (wgrad_x3.hip); same contract
+// f16: 0 = bf16x3, 1 = f16x2 with the absmax slots of x and dy (split16.h)
 int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
-                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
+                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s, int f16 = 0, const unsigned* x_slot = nullptr,
+                    const unsigned* dy_slot = nullptr);
 // stride-1 "same" convolutions on wide maps (wgrad_s1.hip); same contract
 int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s);
 
 // bf16x3 split-precision gather kernel (igemm_bf16x3.hip)
 // `sink` (wpack_state == 1 only): record the packing job there instead of launching anything -- 1 recorded, 0 not eligible
+// f16: 0 = bf16x3, 1 = f16x2 (x_slot: absmax slot of the gathered activation tensor, split16.h)
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s, PackJob* sink = nullptr);          // 1 launched, 0 not eligible, <0 error
+              int wpack_state, hipStream_t s, PackJob* sink = nullptr, int f16 = 0, const unsigned* x_slot = nullptr);          // 1 launched, 0 not eligible, <0 error
 long split_pack_floats_for(const IgemmGeom& f);       // 0 when not eligible
+// the activation operands' absmax slots handed over by faoctasr_conv_set_scales for this thread's next convolution-type call
+extern thread_local const unsigned* g_scale_a;
+extern thread_local const unsigned* g_scale_b;
 
 // Winograd F(2x2,3x3) fp32 kernel for dense stride-1 3x3 gathers (igemm_wino.hip)
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,

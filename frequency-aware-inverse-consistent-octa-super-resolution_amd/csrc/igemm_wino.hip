@@ -537,15 +537,17 @@ long wino_pack_floats_for(const IgemmGeom& f) {
 }
 
 // 1 = enough tiles without splitting; otherwise the number of channel splits that brings the grid to >= 128 blocks (each split keeps
-// >= 2 chunks, divides the chunk count, and the call has no activation), or 0 = leave the shape to the other kernels.
+// >= 2 chunks and divides the chunk count), or 0 = leave the shape to the other kernels.
 // WHETHER this kernel takes a shape must not depend on FAOCTASR_CONV_NO_SPLIT_K: the packed-weight image is recorded (pack plans)
 // without that flag; under it the same shapes run unsplit here (one block owns an output element's whole reduction).
+// ... nor on the fused activation: faoctasr_conv_pack_job records the image with FAOCTASR_ACT_NONE, so a call that fuses an
+// activation (which the atomics of a split cannot apply) runs the same shapes unsplit here too instead of reading the Winograd
+// image as a patch image on another route.
 static int wino_ksplit(const WinoGeom& g, int act) {
     if (wino_worth(g)) return 1;
-    if (act != FAOCTASR_ACT_NONE) return 0;
     const long blocks = wino_tiles(g) * g.mtiles;
     for (int ks = 2; ks <= 16; ks *= 2)
-        if (g.nchunks % ks == 0 && g.nchunks / ks >= 2 && blocks * ks >= 128) return g_no_split_k ? 1 : ks;
+        if (g.nchunks % ks == 0 && g.nchunks / ks >= 2 && blocks * ks >= 128) return (g_no_split_k || act != FAOCTASR_ACT_NONE) ? 1 : ks;
     return 0;
 }
 

@@ -6,6 +6,7 @@
 // (The first version decomposed every ELEMENT with five runtime divisions: the batched launch took 1.18 ms for ~0.5 GB.)
 #pragma once
 #include "igemm_geom.h"
+#include "split16.h"
 
 namespace faoctasr {
 
@@ -69,11 +70,15 @@ __device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, flo
     }
 }
 
-// bf16x3: fp32 W -> two bf16 planes (hi, lo) in the LDS image order  Wp[plane][phase][g16][tap][h][Mpad][8 ch];  row = (phase, g16, tap, h)
+// bf16x3 / f16x2: fp32 W -> two 16-bit planes (hi, lo) in the LDS image order  Wp[plane][phase][g16][tap][h][Mpad][8 ch];  row = (phase, g16, tap, h).
+// F16: the planes hold w * s, s from the weights' absmax slot at the end of the image (written before this runs: split_absmax_block)
 __device__ __forceinline__ long split_pack_rows(const SplitGeom& g) { return g.pack_off[4] / (8L * g.Mpad); }
-__device__ __forceinline__ void split_pack_block(const float* __restrict__ w, __bf16* __restrict__ wp, const SplitGeom& g, long lb, long nb) {
+template <bool F16>
+__device__ __forceinline__ void split_pack_block(const float* __restrict__ w, unsigned short* __restrict__ wp, const SplitGeom& g, long lb, long nb) {
     const long rowlen = 8L * g.Mpad;
     const long nrows = g.pack_off[4] / rowlen;
+    float sc = 1.f;
+    if constexpr (F16) sc = f16x2_scale(reinterpret_cast<const unsigned*>(wp)[split_scale_slot(g)]);
     for (long row = lb; row < nrows; row += nb) {
         int ph = 0;
         while (ph + 1 < g.nphase && row * rowlen >= g.pack_off[ph + 1]) ++ph;
@@ -82,16 +87,39 @@ __device__ __forceinline__ void split_pack_block(const float* __restrict__ w, __
         const int h = (int)(lr & 1); lr >>= 1;
         const int t = (int)(lr % T), g16 = (int)(lr / T);
         const int widx = g.taps[g.t0[ph] + t] >> 16;
-        __bf16* dst = wp + row * rowlen;
+        unsigned short* dst = wp + row * rowlen;
         for (int e = threadIdx.x; e < rowlen; e += 256) {             // e = m*8 + j
             const int j = e & 7, m = e >> 3;
             const int c = g16 * 16 + 8 * h + j;
             float v = 0.f;
-            if (m < g.M && c < g.C) v = w[(long)m * g.wsm + (long)c * g.wsc + widx];
-            const __bf16 hi = (__bf16)v;
-            dst[e] = hi;
-            dst[g.plane_stride + e] = (__bf16)(v - (float)hi);
+            if (m < g.M && c < g.C) v = w[(long)m * g.wsm + (long)c * g.wsc + widx] * sc;
+            unsigned hi, lo;
+            split_pair<F16>(v, 0.f, hi, lo);
+            dst[e] = (unsigned short)hi;
+            dst[g.plane_stride + e] = (unsigned short)lo;
         }
+    }
+}
+
+// the largest |w| of a weight tensor, as its fp32 bit pattern, into the f16x2 image's slot: ONE block per tensor (a layer that takes
+// this route has at most 256 x 256 x 9 weights), so the slot is written once, plainly -- nothing to zero, no atomics
+__device__ __forceinline__ void split_absmax_block(const float* __restrict__ w, float* __restrict__ wp, const SplitGeom& g, unsigned* red /* LDS, 4 words */) {
+    unsigned mx = 0;
+    for (long i = threadIdx.x; i < g.w_elems; i += 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu;
+        mx = b > mx ? b : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = red[0];
+        for (int i = 1; i < 4; ++i) m = red[i] > m ? red[i] : m;
+        reinterpret_cast<unsigned*>(wp)[split_scale_slot(g)] = m;
     }
 }
 

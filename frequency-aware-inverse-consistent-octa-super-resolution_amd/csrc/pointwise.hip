@@ -460,6 +460,35 @@ __global__ void prep_crop_resize_kernel(const unsigned char* __restrict__ img, c
     }
 }
 
+// largest |x| of a tensor as its fp32 bit pattern (non-negative floats order like unsigned integers): the "absmax slot" of the
+// f16x2 contraction (split16.h).  16-byte loads, one atomicMax per wave; NaN / infinity sort above every finite value and leave
+// the tensor unscaled (f16x2_scale).
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ slot) {
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    unsigned mx = 0;
+    const long n4 = n >> 2;
+    const u32x4v* x4 = reinterpret_cast<const u32x4v*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const u32x4v v = x4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned b = v[j] & 0x7fffffffu;
+            mx = b > mx ? b : mx;
+        }
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned b = __builtin_bit_cast(unsigned, x[i]) & 0x7fffffffu;
+        mx = b > mx ? b : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(slot, mx);
+}
+
+
 }  // namespace faoctasr
 
 using namespace faoctasr;
@@ -676,6 +705,14 @@ int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const i
     hipLaunchKernelGGL(prep_crop_resize_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, img, tops, lefts, out, N, H,
                        W, crop, out_size, mean, 1.f / std);
     return check_launch("prep_crop_resize");
+}
+
+int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream) {
+    if (!x || !slot) return fail(FAOCTASR_EINVAL, "absmax_bits: null pointer");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(FAOCTASR_EINVAL, "absmax_bits: x must be 16-byte aligned");
+    if (n <= 0) return FAOCTASR_OK;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(n, 4096, 2048)), dim3(256), 0, (hipStream_t)stream, x, n, slot);
+    return check_launch("absmax_bits");
 }
 
 int faoctasr_adamw_step_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, faoctasr_stream_t stream) {

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "split16.h"
 
 namespace faoctasr {
 
@@ -54,16 +55,6 @@ __device__ __forceinline__ void x3_static_for(F&& f) {
     }
 }
 
-// (a, b) -> packed bf16 hi pair and lo pair (a in the low half): hi = rne(v), lo = rne(v - hi)
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    const bf2 h = {(__bf16)a, (__bf16)b};
-    hi = __builtin_bit_cast(unsigned, h);
-    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
-    const bf2 l = {(__bf16)ra, (__bf16)rb};
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
 template <unsigned IMM>
 __device__ __forceinline__ void x3_read_tr(bf16x4& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM)); }
 template <unsigned IMM>
@@ -79,8 +70,10 @@ __device__ __forceinline__ void x3_wait_set(bf16x8& ah, bf16x8& al, bf16x4 (&bh)
 // loads of tile i + 2 are issued right behind that store -- a whole tile before their use.  Rounds 2's form (256 threads, two blocks
 // per CU alternating) issued a tile's loads and waited for them at once: the ~2.4 us until a burst of loads from every CU has arrived
 // (igemm_bf16x3.hip) were paid per tile and covered only by the other block's MFMAs.
+// F16: f16x2 operands (split16.h): x and dY are staged as x * s(x_slot), dY * s(dy_slot); the scales are divided out before the atomics.
+template <bool F16>
 __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                       const WgX3Geom g) {
+                                                       const WgX3Geom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -114,6 +107,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
 
     if (producer) {
         // ================================================ PRODUCER ================================================
+        float sx = 1.f, sd = 1.f;
+        if constexpr (F16) { sx = f16x2_scale(*x_slot); sd = f16x2_scale(*dy_slot); }
         // ---- staging maps (tile-invariant; addresses of LDS buffer 0) ----
         // dY item i (2 per thread): row m = it >> 3, chunk = it & 7 -> tile row chunk >> 2, pixels 8 (chunk & 3) .. +7
         unsigned dg_off[2], dl_off[2];
@@ -178,10 +173,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                split2(dv[i][0][0], dv[i][0][1], h0, l0);
-                split2(dv[i][0][2], dv[i][0][3], h1, l1);
-                split2(dv[i][1][0], dv[i][1][1], h2, l2);
-                split2(dv[i][1][2], dv[i][1][3], h3, l3);
+                if constexpr (F16) { dv[i][0] *= sd; dv[i][1] *= sd; }
+                split_pair<F16>(dv[i][0][0], dv[i][0][1], h0, l0);
+                split_pair<F16>(dv[i][0][2], dv[i][0][3], h1, l1);
+                split_pair<F16>(dv[i][1][0], dv[i][1][1], h2, l2);
+                split_pair<F16>(dv[i][1][2], dv[i][1][3], h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 const unsigned da = dl_off[i] + bo;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
@@ -191,11 +187,15 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
             for (int i = 0; i < 3; ++i) {
                 if (x_row[i] < 0) continue;
                 const unsigned xa = xl_off[i] + bo;
+                if constexpr (F16) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xv[i][c] *= sx;
+                }
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {                         // one pixel's four channels -> 8 bytes per plane
                     unsigned h0, h1, l0, l1;
-                    split2(xv[i][0][px], xv[i][1][px], h0, l0);
-                    split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                    split_pair<F16>(xv[i][0][px], xv[i][1][px], h0, l0);
+                    split_pair<F16>(xv[i][2][px], xv[i][3][px], h1, l1);
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3_XPLANE) : "memory");
@@ -267,9 +267,9 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
                     const bf16x8 b_hi = __builtin_shufflevector(bh[set][kw][0], bh[set][kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x8 b_lo = __builtin_shufflevector(bl[set][kw][0], bl[set][kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
                     f32x16& d = acc[kh * 3 + kw];
-                    if constexpr (term == 0) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ab], b_hi, d, 0, 0, 0);
-                    else if constexpr (term == 1) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ab], b_lo, d, 0, 0, 0);
-                    else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[ab], b_hi, d, 0, 0, 0);
+                    if constexpr (term == 0) mfma16<F16>(a_lo[ab], b_hi, d);
+                    else if constexpr (term == 1) mfma16<F16>(a_hi[ab], b_lo, d);
+                    else mfma16<F16>(a_hi[ab], b_hi, d);
                     if constexpr (s + 1 < 12 && m < 7) {
                         rd(std::integral_constant<int, s + 1>{}, std::integral_constant<int, 2 * m>{});
                         rd(std::integral_constant<int, s + 1>{}, std::integral_constant<int, 2 * m + 1>{});
@@ -285,12 +285,14 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
     // per wave and pass: 8 rows x 32 channels x 9 taps = 2304 floats (9216 B); the four waves use disjoint regions
     float* stage = reinterpret_cast<float*>(smem) + wave * 2304;
     const long col_base = (long)(c0 + cb * 32) * g.wsc;
+    float inv = 1.f;
+    if constexpr (F16) inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*dy_slot);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                                        // rows 8 j .. 8 j + 7 of the wave's 32 = registers 4 j .. 4 j + 3 of both lane halves
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * 9 + t] = acc[t][4 * j + r];
+            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * 9 + t] = F16 ? acc[t][4 * j + r] * inv : acc[t][4 * j + r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -335,9 +337,9 @@ struct WgX3RowGeom {
     int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges (x KH kernel rows)
 };
 
-template <int KW, int S, int PAD>
+template <int KW, int S, int PAD, bool F16>
 __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                           const WgX3RowGeom g) {
+                                                           const WgX3RowGeom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot) {
     // wave-specialised like wgrad_x3_kernel (round 3): waves 0-3 contract, waves 4-7 stage into a double-buffered LDS image, a tile ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -375,6 +377,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     const unsigned d_lds0 = lds0, x_lds0 = lds0 + 2 * X3_DPLANE;
 
     if (producer) {
+        float sx = 1.f, sd = 1.f;
+        if constexpr (F16) { sx = f16x2_scale(*x_slot); sd = f16x2_scale(*dy_slot); }
         unsigned dg_off[2], dl_off[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -441,10 +445,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                split2(dv[i][0][0], dv[i][0][1], h0, l0);
-                split2(dv[i][0][2], dv[i][0][3], h1, l1);
-                split2(dv[i][1][0], dv[i][1][1], h2, l2);
-                split2(dv[i][1][2], dv[i][1][3], h3, l3);
+                if constexpr (F16) { dv[i][0] *= sd; dv[i][1] *= sd; }
+                split_pair<F16>(dv[i][0][0], dv[i][0][1], h0, l0);
+                split_pair<F16>(dv[i][0][2], dv[i][0][3], h1, l1);
+                split_pair<F16>(dv[i][1][0], dv[i][1][1], h2, l2);
+                split_pair<F16>(dv[i][1][2], dv[i][1][3], h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 const unsigned da = dl_off[i] + bo;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
@@ -456,15 +461,16 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                 const unsigned xa = xl_off[i] + bo;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                            // mirrored border chunks (reflection only)
-                    const f32x4 v = xv[i][c];
+                    f32x4 v = xv[i][c];
+                    if constexpr (F16) v *= sx;
                     const f32x4 l = {v[0], v[3], v[2], v[1]}, r = {v[2], v[1], v[0], v[3]};
                     xv[i][c] = flip[i] == 1 ? l : (flip[i] == 2 ? r : v);
                 }
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
                     unsigned h0, h1, l0, l1;
-                    split2(xv[i][0][px], xv[i][1][px], h0, l0);
-                    split2(xv[i][2][px], xv[i][3][px], h1, l1);
+                    split_pair<F16>(xv[i][0][px], xv[i][1][px], h0, l0);
+                    split_pair<F16>(xv[i][2][px], xv[i][3][px], h1, l1);
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + R::XPLANE) : "memory");
@@ -530,9 +536,9 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                 const bf16x8 b_hi = __builtin_shufflevector(bh[kw][0], bh[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 b_lo = __builtin_shufflevector(bl[kw][0], bl[kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 f32x16& d = acc[kw];
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, d, 0, 0, 0);
+                mfma16<F16>(a_lo, b_hi, d);
+                mfma16<F16>(a_hi, b_lo, d);
+                mfma16<F16>(a_hi, b_hi, d);
             }
         });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every read of this buffer retired; the next tile is staged
@@ -541,12 +547,14 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     // ---- epilogue: [m][channel] per tap -> dW[m][c][kh][0..KW) through LDS, atomics in runs of KW floats per channel ----
     float* stage = reinterpret_cast<float*>(smem) + wave * (8 * 32 * KW);
     const long col_base = (long)(c0 + cb * 32) * g.wsc + (long)kh * KW;
+    float inv = 1.f;
+    if constexpr (F16) inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*dy_slot);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int t = 0; t < KW; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * KW + t] = acc[t][4 * j + r];
+            for (int r = 0; r < 4; ++r) stage[((r + 4 * lh) * 32 + l31) * KW + t] = F16 ? acc[t][4 * j + r] * inv : acc[t][4 * j + r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -564,25 +572,30 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     }
 }
 
-template <int KW, int S, int PAD>
-static int x3_row_go(const float* x, const float* dy, float* dw, WgX3RowGeom& g, hipStream_t s) {
+template <int KW, int S, int PAD, bool F16>
+static int x3_row_go2(const float* x, const float* dy, float* dw, WgX3RowGeom& g, hipStream_t s, const unsigned* x_slot, const unsigned* dy_slot) {
     const long ntiles = (long)g.N * g.tiles_y * g.tiles_x;
     long slices = 256 / ((long)g.gx * g.gy * g.KH);                      // one 512-thread block per CU
     if (slices < 1) slices = 1;
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    auto k = wgrad_x3_row_kernel<KW, S, PAD>;
+    auto k = wgrad_x3_row_kernel<KW, S, PAD, F16>;
     const size_t lds = 2 * (size_t)X3R<S>::LDS > (size_t)4 * 8 * 32 * KW * 4 ? 2 * (size_t)X3R<S>::LDS : (size_t)4 * 8 * 32 * KW * 4;
     lds_optin((const void*)k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.KH * g.slices)), dim3(512), lds, s, x, dy, dw, g);
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.KH * g.slices)), dim3(512), lds, s, x, dy, dw, g, x_slot, dy_slot);
     const int rc = check_launch("wgrad_x3_row");
     return rc == FAOCTASR_OK ? 1 : rc;
+}
+template <int KW, int S, int PAD>
+static int x3_row_go(const float* x, const float* dy, float* dw, WgX3RowGeom& g, hipStream_t s, int f16, const unsigned* x_slot, const unsigned* dy_slot) {
+    return f16 ? x3_row_go2<KW, S, PAD, true>(x, dy, dw, g, s, x_slot, dy_slot) : x3_row_go2<KW, S, PAD, false>(x, dy, dw, g, s, x_slot, dy_slot);
 }
 
 // one kernel row per block: 7x7 pad 3 stride 1 ("same", reflection or zero padding); 4x4 and 3x3 pad 1 stride 2 (zero padding, IH = 2 OH)
 static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
-                               int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
+                               int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s, int f16, const unsigned* x_slot,
+                               const unsigned* dy_slot) {
     if (KH != KW || (C & 63) || (M & 63) || (OW & 31) || (OH & 1) || (IW & 3) || wsc != (long)KH * KW) return 0;
     if ((long)64 * IH * IW >= (1L << 29) || (long)64 * OH * OW >= (1L << 29)) return 0;      // 32-bit byte offsets inside a 64-channel slab
     WgX3RowGeom g;
@@ -591,19 +604,21 @@ static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N
     g.gx = C / 64; g.gy = M / 64;
     if (stride == 1 && KH == 7 && pad == 3 && OH == IH && OW == IW) {
         if (reflect && (IH <= pad || IW < 8)) return 0;
-        return x3_row_go<7, 1, 3>(x, dy, dw, g, s);
+        return x3_row_go<7, 1, 3>(x, dy, dw, g, s, f16, x_slot, dy_slot);
     }
     if (stride == 2 && pad == 1 && !reflect && IH == 2 * OH && IW == 2 * OW) {
-        if (KH == 4) return x3_row_go<4, 2, 1>(x, dy, dw, g, s);
-        if (KH == 3) return x3_row_go<3, 2, 1>(x, dy, dw, g, s);
+        if (KH == 4) return x3_row_go<4, 2, 1>(x, dy, dw, g, s, f16, x_slot, dy_slot);
+        if (KH == 3) return x3_row_go<3, 2, 1>(x, dy, dw, g, s, f16, x_slot, dy_slot);
     }
     return 0;
 }
 
 // returns 1 when launched, 0 when the shape is left to the fp32 kernels, <0 on error.  dw zeroed / accumulating, as elsewhere.
 int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
-                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s) {
-    if ((stride == 1 && KH == 7) || stride == 2) return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, wsm, wsc, s);
+                    int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s, int f16, const unsigned* x_slot, const unsigned* dy_slot) {
+    if (f16 && (!x_slot || !dy_slot)) return fail(FAOCTASR_EINVAL, "wgrad f16x2: missing absmax slots");
+    if ((stride == 1 && KH == 7) || stride == 2)
+        return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, wsm, wsc, s, f16, x_slot, dy_slot);
     if (stride != 1 || KH != 3 || KW != 3 || pad != 1 || reflect || OH != IH || OW != IW) return 0;
     if ((C & 63) || (M & 63) || (OW & 31) || (OH & 1) || wsc != 9) return 0;
     if ((long)64 * IH * IW >= (1L << 29)) return 0;                      // 32-bit byte offsets inside a 64-channel slab
@@ -617,8 +632,13 @@ int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, in
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    lds_optin((const void*)wgrad_x3_kernel, 2 * X3_LDS);
-    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g);
+    if (f16) {
+        lds_optin((const void*)wgrad_x3_kernel<true>, 2 * X3_LDS);
+        hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot);
+    } else {
+        lds_optin((const void*)wgrad_x3_kernel<false>, 2 * X3_LDS);
+        hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot);
+    }
     const int rc = check_launch("wgrad_x3");
     return rc == FAOCTASR_OK ? 1 : rc;
 }

@@ -42,9 +42,10 @@ import weakref
 weight_epoch = 0
 use_wpack = True
 #: convolution arithmetic: 0 = fp32 MFMA with Winograd F(2x2,3x3) on the stride-1 3x3 layers (default), 1 = fp32 MFMA direct only,
-#: 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate)
+#: 2 = bf16x3 split operands (fp32-parity, ~5x MFMA rate); 3 = f16x2 split operands with per-tensor power-of-two scales (error at
+#: or below the exact-f32 kernels', same rate as bf16x3: csrc/split16.h)
 conv_precision = 0
-PRECISIONS = {"f32": 0, "f32_direct": 1, "bf16x3": 2}
+PRECISIONS = {"f32": 0, "f32_direct": 1, "bf16x3": 2, "f16x2": 3}
 #: FAOCTASR_CONV_NO_SPLIT_K (include/faoctasr.h) on every FORWARD convolution: no fp32 atomics in the forward pass, so its
 #: activations -- and with them every ReLU / LeakyReLU mask the backward uses -- are bit-reproducible from run to run
 reproducible_forward = False
@@ -57,6 +58,52 @@ pack_misses = 0
 def invalidate_weight_cache():
     global weight_epoch
     weight_epoch += 1
+
+
+# ----------------------------------------------------------------------------------------
+# absmax slots of the f16x2 contraction (include/faoctasr.h: faoctasr_absmax_bits, faoctasr_conv_set_scales)
+# ----------------------------------------------------------------------------------------
+#: per HIP stream: (zeroed fp32 arena, cursor).  A slot is one word holding max|x| of an activation tensor (its fp32 bit pattern IS
+#: the float).  One arena per stream, because a slot is zeroed, filled and first read in stream order -- handing slots of one
+#: arena to several streams would let a reader overtake the fill.
+_scale_arenas = {}
+SCALE_ARENA_SLOTS = 2048
+
+
+def reset_scale_arenas():
+    """Drop the arenas (their slots stay alive while something references them): the next slot comes from a freshly zeroed
+    arena.  ``GraphedTrainStep`` calls it around a capture so that every slot of the graph is zeroed INSIDE the graph."""
+    _scale_arenas.clear()
+
+
+def _new_slot(device):
+    sid = stream_ptr()
+    ent = _scale_arenas.get(sid)
+    if ent is None or ent[1] >= SCALE_ARENA_SLOTS or ent[0].device != device:
+        ent = _scale_arenas[sid] = [torch.zeros(SCALE_ARENA_SLOTS, dtype=torch.float32, device=device), 0]
+    i = ent[1]
+    ent[1] = i + 1
+    return ent[0][i:i + 1]
+
+
+def absmax_slot(t):
+    """The absmax slot of activation tensor ``t`` for a convolution enqueued on the CURRENT stream.  Cached on the tensor object for
+    further uses on the same stream while the tensor is unchanged (the skip connection and the first convolution of a residual
+    block read the same tensor); a producer that computes the maximum in its own epilogue may pre-set ``t._fa_absmax``."""
+    sid = stream_ptr()
+    c = getattr(t, "_fa_absmax", None)
+    if c is not None and c[1] == t._version and c[2] == sid:
+        return c[0]
+    slot = _new_slot(t.device)
+    call("absmax_bits", ptr(t), t.numel(), ptr(slot), sid)
+    t._fa_absmax = (slot, t._version, sid)
+    return slot
+
+
+def _wants_scale(C, IW, OW):
+    """Superset of the shapes the split kernels take (csrc/igemm_bf16x3.hip: >= 16 gathered channels, grid width >= 24;
+    csrc/wgrad_x3.hip: channel counts in multiples of 64, width in multiples of 32): maps narrower than that never read a slot."""
+    return conv_precision == 3 and C >= 16 and max(IW, OW) >= 24
 
 
 class _PackEntry:
@@ -102,6 +149,8 @@ def _wpack(w, kind, dims, reflect=0, out_pad=0):
         if ent.event is not None:
             cur = torch.cuda.current_stream()
             if cur.cuda_stream != ent.ev_stream:         # packed inline on another stream: order this reader behind that launch
+                if wait_guard is not None:
+                    wait_guard(cur.cuda_stream, ent.ev_stream)
                 cur.wait_event(ent.event)
         return ent.buf, 2, ent
     ent.ver = ver
@@ -132,6 +181,7 @@ class PackPlan:
         ids = {id(p) for p in params}
         slot = ctypes.create_string_buffer(_lib.PACK_JOB_BYTES)
         blobs, base, self.entries, device = [], 0, [], None
+        self.precision = precision
         for key, e in list(_wpack_cache.items()):
             w = e.wref()
             if w is None or id(w) not in ids or e.precision != precision or not e.touched:
@@ -154,6 +204,8 @@ class PackPlan:
         if any(w is None or w.data_ptr() != p for (e, w), (_, p) in zip(live, self.entries)):
             return False
         if self.njobs:
+            if self.precision == 3:                 # f16x2 images: the weights' absmax slots first
+                call("conv_pack_scales", ptr(self.table), self.njobs, stream_ptr())
             call("conv_pack_run", ptr(self.table), self.njobs, self.nblocks, stream_ptr())
         for e, w in live:
             e.ver = _ver(w)
@@ -169,6 +221,8 @@ class PackPlan:
 #: reads it.
 wgrad_stream = None
 _wgrad_keep = {}
+#: ``f(waiter_stream_id, waited_stream_id)`` called before each cross-stream wait issued here (train._CaptureGuard.edge)
+wait_guard = None
 
 
 def _enqueue_wgrad(fn, *operands):
@@ -179,6 +233,8 @@ def _enqueue_wgrad(fn, *operands):
         return
     cur = torch.cuda.current_stream()
     if cur.cuda_stream != side.cuda_stream:
+        if wait_guard is not None:
+            wait_guard(side.cuda_stream, cur.cuda_stream)
         side.wait_stream(cur)
     with torch.cuda.stream(side):
         fn(side.cuda_stream)
@@ -190,6 +246,8 @@ def join_wgrad_stream(side):
     if side is not None:
         cur = torch.cuda.current_stream()
         if cur.cuda_stream != side.cuda_stream:
+            if wait_guard is not None:
+                wait_guard(cur.cuda_stream, side.cuda_stream)
             cur.wait_stream(side)
         _wgrad_keep.pop(side.cuda_stream, None)
 
@@ -218,9 +276,13 @@ class _Conv2d(Function):
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
+        sx = absmax_slot(x) if _wants_scale(C, IW, OW) else None
+        if sx is not None:
+            call("conv_set_scales", ptr(sx), None)
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
              conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
         _packed(ent, wst)
+        ctx.sx = sx
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
         ctx.cfg = (stride, pad, reflect, act, slope)
@@ -239,7 +301,10 @@ class _Conv2d(Function):
             call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
             dy = g
         dx = dw = db = None
+        sdy = absmax_slot(dy) if _wants_scale(M, IW, dy.shape[3]) else None
         if ctx.needs_input_grad[0]:
+            if sdy is not None:
+                call("conv_set_scales", ptr(sdy), None)
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
                 wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
@@ -258,11 +323,21 @@ class _Conv2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             prec = conv_precision
+            sx = ctx.sx
+            if prec == 3 and sdy is not None and sx is None:
+                sx = absmax_slot(x)
+            if prec == 3 and (sx is None or sdy is None):
+                prec = 0                               # a map too narrow for the split kernels: the exact-f32 kernels, no slots
+                sx = sdy = None
+
+            def wgrad(s, out, accumulate):
+                if sx is not None:
+                    call("conv_set_scales", ptr(sx), ptr(sdy))
+                call("conv2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, prec, s)
             if tgt is not None:
-                _enqueue_wgrad(lambda s: call("conv2d_wgrad", ptr(x), ptr(dy), ptr(tgt), N, C, IH, IW, M, KH, KW, stride, pad, reflect, 1, prec, s),
-                               x, dy)
+                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
             else:
-                call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, IH, IW, M, KH, KW, stride, pad, reflect, 0, prec, st)
+                wgrad(st, dw, 0)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
             tb = _grad_target(ctx.b_ref)
             if tb is not None:
@@ -288,6 +363,10 @@ class _ConvTranspose2d(Function):
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
+        sx = absmax_slot(x) if _wants_scale(C, IW, OW) else None
+        if sx is not None:
+            call("conv_set_scales", ptr(sx), None)
+        ctx.sx = sx
         call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
              ptr(wp), wst, conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
         _packed(ent, wst)
@@ -309,9 +388,12 @@ class _ConvTranspose2d(Function):
             call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
             dy = g
         dx = dw = db = None
+        sdy = absmax_slot(dy) if _wants_scale(M, IW, dy.shape[3]) else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp, wst, ent = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
+            if sdy is not None:
+                call("conv_set_scales", ptr(sdy), None)
             call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
                  conv_precision, st)
             _packed(ent, wst)
@@ -320,11 +402,21 @@ class _ConvTranspose2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             prec = conv_precision
+            sx = ctx.sx
+            if prec == 3 and sdy is not None and sx is None:
+                sx = absmax_slot(x)
+            if prec == 3 and (sx is None or sdy is None):
+                prec = 0
+                sx = sdy = None
+
+            def wgrad(s, out, accumulate):
+                if sx is not None:
+                    call("conv_set_scales", ptr(sx), ptr(sdy))
+                call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, accumulate, prec, s)
             if tgt is not None:
-                _enqueue_wgrad(lambda s: call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(tgt), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, 1,
-                                              prec, s), x, dy)
+                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
             else:
-                call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, 0, prec, st)
+                wgrad(st, dw, 0)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
             tb = _grad_target(ctx.b_ref)
             if tb is not None:

@@ -140,11 +140,55 @@ class ParamArena:
         return [lr, b1, b2, f32(self.eps), f32(self.weight_decay), f32(lr / bc1), f32(1.0 / math.sqrt(bc2)), f32(grad_scale)]
 
 
+class _CaptureGuard:
+    """Host-side record of the waits issued between FORKED streams while a hipGraph capture is open.
+
+    ROCm 7.2's ``hip::Stream::EndCapture`` walks each forked stream's list of "parallel capture streams" (the streams that waited
+    on one of its events) recursively and without a visited set: a cycle among those waits -- two forked streams that wait on each
+    other -- recurses until the stack overflows and the process dies with SIGSEGV in ``hipStreamEndCapture`` (DESIGN.md 4.4a,
+    profiles/r03_capture_crash_gdb_*.log, tools/probe/capture_fork_join.hip).  Waits to and from the capture's origin stream are not
+    listed.  ``edge`` is called before every cross-stream wait of the schedule; a wait that would close a cycle raises
+    ``KernelError`` instead of being issued, so a ``stream_layout`` or schedule change that breaks the rule fails as a Python
+    exception at capture time, not as a crash at the end of it."""
+
+    def __init__(self):
+        self.origin = None
+        self.edges = {}
+
+    def begin(self, origin_sid):
+        self.origin, self.edges = origin_sid, {}
+
+    def end(self):
+        self.origin, self.edges = None, {}
+
+    def edge(self, waiter_sid, on_sid):
+        """Record "waiter waits on an event of on"; raises if that closes a cycle among forked streams."""
+        if self.origin is None or waiter_sid == on_sid or waiter_sid == self.origin or on_sid == self.origin:
+            return
+        stack, seen = [on_sid], {on_sid}
+        while stack:                                   # does `on` already (transitively) wait on `waiter`?
+            n = stack.pop()
+            if n == waiter_sid:
+                raise KernelError("hipGraph capture: stream %#x would wait on stream %#x, which already waits on it -- a cycle of waits among "
+                                  "forked capture streams crashes hipStreamEndCapture on ROCm 7.2 (DESIGN.md 4.4a); keep the role both depend "
+                                  "on on the capture's origin stream" % (waiter_sid, on_sid))
+            for m in self.edges.get(n, ()):
+                if m not in seen:
+                    seen.add(m)
+                    stack.append(m)
+        self.edges.setdefault(waiter_sid, set()).add(on_sid)
+
+
+_guard = _CaptureGuard()
+ops.wait_guard = _guard.edge          # the weight-gradient side stream's waits (ops._enqueue_wgrad / join_wgrad_stream) report here too
+
+
 def _wait(waiter, on):
     """``waiter.wait_stream(on)`` unless both roles are the same stream (``TrainStep.stream_layout``).  A stream waiting on its own
     event is a no-op eagerly; inside a hipGraph capture it is not harmless on ROCm 7.2 (tools/probe/capture_fork_join.hip,
     profiles/r03_capture_probe.log), and it is never needed, so it is never issued."""
     if waiter.cuda_stream != on.cuda_stream:
+        _guard.edge(waiter.cuda_stream, on.cuda_stream)
         waiter.wait_stream(on)
 
 
@@ -154,6 +198,7 @@ def _join(waiter, streams):
     for st in streams:
         if st is not None and st.cuda_stream not in seen:
             seen.add(st.cuda_stream)
+            _guard.edge(waiter.cuda_stream, st.cuda_stream)
             waiter.wait_stream(st)
 
 
@@ -168,6 +213,7 @@ class _Mark:
 def _after(waiter, mark):
     """``waiter`` continues after ``mark`` (no-op for None or a mark of the same stream)."""
     if mark is not None and waiter.cuda_stream != mark.sid:
+        _guard.edge(waiter.cuda_stream, mark.sid)
         waiter.wait_event(mark.event)
 
 
@@ -204,8 +250,10 @@ class TrainStep:
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
                  process_group=None, distributed=None, init=True, precision="f32", overlap_wgrad=True,
                  reproducible_forward=False):
-        """``precision``: "f32" = exact fp32 MFMA contraction (default); "bf16x3" = forward / input-gradient convolutions on
-        the bf16 matrix cores with hi/lo-split operands (fp32-parity: step-0 losses within ~1e-4; weight gradients stay fp32)."""
+        """``precision``: "f32" = exact fp32 MFMA contraction (default); "bf16x3" = the convolutions' three GEMMs on the bf16 matrix
+        cores with hi/lo-split operands (16 significant bits: step-0 losses within ~1e-4 of "f32"); "f16x2" = the same kernels on
+        fp16 hi/lo-split operands scaled per tensor by a power of two (22 significant bits; per-layer error against fp64 at or below
+        the exact-f32 kernels', csrc/split16.h).  Maps narrower than 24 and 1-channel stems / heads run on the f32 kernels in every mode."""
         if precision not in ops.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(ops.PRECISIONS))
         self.precision = precision
@@ -373,151 +421,45 @@ class TrainStep:
                 _wait(main, st)
         return o
 
-    def _generators_two_chains(self, real_A, real_B):
+    def _generators_two_chains(self, real_A, real_B, chain_A_forked):
         """The generator phase (train.py:173-236) as two chains on two streams:
 
-            chain A (caller's stream):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
-            chain B (stream ``_aba``):  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
-            identity passes (``_idt``) with their loss terms and backward; the frozen discriminator of chain A on a branch stream,
-            the one of chain B on chain B's own stream
+            chain A:  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
+            chain B:  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
+            identity passes (stream ``_idt``) with their loss terms and backward; each chain's frozen discriminator on a branch stream
 
         Chain A's loss terms depend on nothing chain B computes, so its backward -- a third of the generators' backward work -- runs
         under chain B's forward.  Each network's three passes keep the reference's order (A2B: real_A, real_B, fake_A; B2A: real_A,
-        fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence.  Returns (o, L, root):
-        ``root`` is what is left to back-propagate (chain B's terms).
+        fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence; a discriminator's
+        frozen pass is ordered before its update phase the same way (its running statistics are plain read-modify-writes).
+        Returns (o, L, root): ``root`` is what is left to back-propagate (chain B's terms); every total that mixes streams is formed
+        by ``step`` after it has joined them (``_chain_B_terms``).
 
-        Which chain sits on which stream is dictated by hipGraph capture (profiles/r03_capture_crash_gdb_*.log): when a
-        forked stream waits on an event of another forked stream, the HIP runtime lists the waiter as a "parallel capture stream" of
-        the other, and ``hip::Stream::EndCapture`` walks those lists recursively without a visited set -- two forked streams that
-        wait on each other (round 2's layout: chain A on a forked stream needed an identity-pass event and the identity stream
-        needed a chain-A event) recurse until the stack overflows.  Waits to and from the capture's ORIGIN stream are never listed.
-        So the chain both other roles depend on runs on the caller's stream (the origin under capture), and among the forked streams
-        the waits form a DAG: ``_idt`` waits only on the caller, ``_aba`` on the caller and on ``_idt``, the weight-gradient stream
-        on everybody, nobody but the caller on it."""
+        ``chain_A_forked`` says which chain sits on the caller's stream; the other one runs on ``_aba``.
+          * False -- chain A on the caller's stream: the ONLY arrangement a hipGraph capture can hold.  When a forked stream waits on
+            an event of another forked stream, the HIP runtime lists the waiter as a "parallel capture stream" of the other, and
+            ``hip::Stream::EndCapture`` walks those lists recursively without a visited set: two forked streams that wait on each
+            other recurse until the stack overflows (profiles/r03_capture_crash_gdb_*.log).  Waits to and from the
+            capture's ORIGIN stream are never listed.  With chain A -- which both other roles depend on -- on the origin, the waits
+            among forked streams form a DAG: ``_idt`` waits only on the caller, ``_aba`` on the caller and on ``_idt``, chain B's
+            frozen discriminator runs on chain B's own stream.  ``_CaptureGuard`` enforces the rule.
+          * True -- chain A on ``_aba``, chain B on the caller's (eager steps only, ``eager_chain_A_forked``: 109.7 against 111.4 ms
+            at batch 8): ``_idt`` then waits on an ``_aba`` event and ``_aba`` on an ``_idt`` event -- harmless outside a capture."""
         G_A2B, G_B2A, w = self.netG_A2B, self.netG_B2A, self.w
         ones, _ = self.targets(real_A.shape[0])
         main = torch.cuda.current_stream(self.device)
-        Q, I, side = self._aba, self._idt, self._wgrad_side()
-        cB = self._branch[1]
-        if cB.cuda_stream == Q.cuda_stream:      # chain A's frozen discriminator must not share chain B's stream (it would wait on the caller
-            cB = self._branch[0]                 # and be waited on by it from inside chain B's work); any other branch stream will do
+        SA, SB = (self._aba, main) if chain_A_forked else (main, self._aba)
+        I, side = self._idt, self._wgrad_side()
+        cB = self._branch[1]                     # chain A's frozen discriminator (D_B): a branch stream other than chain B's
+        if cB.cuda_stream == SB.cuda_stream:
+            cB = self._branch[0]
+        cA = self._branch[0] if chain_A_forked else SB     # chain B's frozen discriminator (D_A): on chain B's own stream when that is forked
         o, L = {}, {}
         hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the caller's stream
         hfB, lfB = ops.freq_split(real_B, 5, 14)
         ev_in = _Mark(main)
         for t in (hfA, lfA, hfB, lfB, real_A, real_B):
-            t.record_stream(Q)
-            t.record_stream(I)
-
-        def identity(net, first, second, real, key, after):
-            _after(I, after)                                # always an event of the caller's stream
-            with torch.cuda.stream(I):
-                _, _, o[key] = net(first, second)
-                ev = _Mark(I)
-                term = ops.l1_loss(real, o[key], w["beta2"])
-                ops.wgrad_stream = side
-                try:
-                    term.backward()
-                finally:
-                    ops.wgrad_stream = None
-            o[key].record_stream(main)
-            term.record_stream(main)
-            return ev, term.detach()
-
-        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", ev_in)                 # B2A pass 1
-        # ---- chain A, forward (caller's stream)
-        _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                      # A2B pass 1
-        ev_a2b_1 = _Mark(main)
-        o["hf_feature_A"] = hf_feature_A.detach()
-        _wait(cB, main)
-        o["fake_B"].record_stream(cB)
-        with torch.cuda.stream(cB):
-            pred_B = self.netD_B(o["fake_B"])
-            ev_pred_B = _Mark(cB)
-        hf, lf = ops.freq_split(o["fake_B"], 5, 14)
-        _after(main, ev_idt_A)
-        o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                    # B2A pass 2
-        ev_b2a_2 = _Mark(main)
-        # ---- chain B, forward (its own stream), enqueued before chain A's backward so that the two overlap
-        _after(Q, ev_b2a_2)                                                                 # (implies ev_in)
-        with torch.cuda.stream(Q):
-            hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                  # B2A pass 3
-            o["hf_feature_B"] = hf_feature_B.detach()
-            ev_fake_A = _Mark(Q)
-            pred_A = self.netD_A(o["fake_A"])                                               # chain B's frozen discriminator, on chain B's stream
-            hf, lf = ops.freq_split(o["fake_A"], 10, 8)
-        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2 (after pass 1 on the caller's stream)
-        _after(Q, ev_idt_B)
-        with torch.cuda.stream(Q):
-            _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                # A2B pass 3
-            L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
-            L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
-                ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
-            root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
-            extra_B = self._extension_terms(o["recovered_B"], real_B)       # opt-in SSIM / wavelet-HF terms: one half per chain
-            for k, v in extra_B.items():
-                root = root + v
-        # ---- chain A, losses and backward (caller's stream)
-        _after(main, ev_pred_B)
-        pred_B.record_stream(main)
-        L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
-        L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
-        chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
-        extra_A = self._extension_terms(o["recovered_A"], real_A)
-        for k, v in extra_A.items():
-            chain_A = chain_A + v
-        ops.wgrad_stream = side
-        try:
-            chain_A.backward()
-        finally:
-            ops.wgrad_stream = None
-        # ---- the caller's stream picks up what chain B has produced so far (fake_A feeds the replay buffer and the discriminator phase;
-        # the loss scalars are read after the step's final joins)
-        _after(main, ev_fake_A)
-        done = None
-        for k, v in extra_B.items():
-            v.record_stream(main)
-            done = extra_A[k].detach() if done is None else done + extra_A[k].detach()
-        for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
-            L[k] = L[k].detach()
-        for k in ("fake_A", "hf_feature_B", "hf_feature_recovered_B", "recovered_B"):
-            o[k].record_stream(main)
-        for k in ("loss_GAN_B2A", "loss_cycle_BAB"):
-            L[k].record_stream(main)
-        root.record_stream(main)
-        L["loss_idt"] = idt_A + idt_B
-        o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
-        # totals that mix the two chains are formed by ``step`` after it has joined chain B's stream
-        self._chain_B_terms = (root, L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"], done,
-                               {k: (extra_A[k].detach(), v) for k, v in extra_B.items()})
-        return o, L, root
-
-    def _generators_two_chains_eager(self, real_A, real_B):
-        """Round 2's arrangement of ``_generators_two_chains``, kept for eager (un-captured) steps when ``eager_chain_A_forked`` is set:
-        chain A on the forked stream ``_aba`` and chain B on the caller's.  It cannot be captured (its two forked streams wait on each
-        other: see ``_generators_two_chains``); outside a capture that is harmless.
-
-        The generator phase (train.py:173-236) as two chains on two streams:
-
-            chain A (stream ``_aba``):  fake_B = A2B(real_A), recovered_A = B2A(fake_B), loss_cycle_ABA + loss_GAN_A2B, THEIR BACKWARD
-            chain B (main stream)    :  fake_A = B2A(real_B), recovered_B = A2B(fake_A), loss_cycle_BAB + loss_GAN_B2A
-            identity passes (``_idt``) and the frozen discriminator passes (branch streams) as in ``forward_generators``
-
-        Chain A's loss terms depend on nothing chain B computes, so its backward -- a third of the generators' backward work -- runs
-        under chain B's forward.  Each network's three passes keep the reference's order (A2B: real_A, real_B, fake_A; B2A: real_A,
-        fake_B, real_B) through events, so the BatchNorm running statistics are updated in the same sequence.  Returns (o, L, root):
-        ``root`` is what is left to back-propagate (chain B's terms)."""
-        G_A2B, G_B2A, w = self.netG_A2B, self.netG_B2A, self.w
-        ones, _ = self.targets(real_A.shape[0])
-        main = torch.cuda.current_stream(self.device)
-        X, I, side = self._aba, self._idt, self._side
-        cA, cB = self._branch
-        o, L = {}, {}
-        hfA, lfA = ops.freq_split(real_A, 10, 8)            # both filter pairs are (first) used on the main stream
-        hfB, lfB = ops.freq_split(real_B, 5, 14)
-        ev_in = _Mark(main)
-        for t in (hfA, lfA, hfB, lfB, real_A, real_B):
-            t.record_stream(X)
+            t.record_stream(self._aba)
             t.record_stream(I)
 
         def identity(net, first, second, real, key, after):
@@ -532,30 +474,54 @@ class TrainStep:
                     term.backward()
                 finally:
                     ops.wgrad_stream = None
-            o[key].record_stream(main)
-            term.record_stream(main)
             return ev, term.detach()
 
         def critic(net, fake, st, src):
+            """The frozen discriminator pass of ``fake`` (made on ``src``) on ``st``: (prediction, mark after it)."""
             _wait(st, src)
             fake.record_stream(st)
             with torch.cuda.stream(st):
                 pred = net(fake)
-            return pred, _Mark(st)
+                return pred, _Mark(st)
 
-        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                   # B2A pass 1
-        _after(X, ev_in)
-        with torch.cuda.stream(X):
+        ev_idt_A, idt_A = identity(G_B2A, hfA, lfA, real_A, "idt_A", None)                  # B2A pass 1
+        # ---- chain A, forward
+        _after(SA, ev_in)
+        with torch.cuda.stream(SA):
             _, hf_feature_A, o["fake_B"] = G_A2B(lfA, hfA)                                  # A2B pass 1
-            ev_a2b_1 = _Mark(X)
+            ev_a2b_1 = _Mark(SA)
             o["hf_feature_A"] = hf_feature_A.detach()
-            pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, X)
+            pred_B, ev_pred_B = critic(self.netD_B, o["fake_B"], cB, SA)
             hf, lf = ops.freq_split(o["fake_B"], 5, 14)
-            _after(X, ev_idt_A)
+            _after(SA, ev_idt_A)
             o["hf_feature_recovered_A"], _, o["recovered_A"] = G_B2A(hf, lf)                # B2A pass 2
-            ev_b2a_2 = _Mark(X)
-            _after(X, ev_pred_B)                 # (layout "001212": chain A and critic B share a stream -- no wait is issued then)
-            pred_B.record_stream(X)
+            ev_b2a_2 = _Mark(SA)
+        # ---- chain B, forward; enqueued before chain A's backward so that the two overlap
+        _after(SB, ev_in)
+        _after(SB, ev_b2a_2)
+        with torch.cuda.stream(SB):
+            hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                  # B2A pass 3
+            o["hf_feature_B"] = hf_feature_B.detach()
+            ev_fake_A = _Mark(SB)
+            pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, SB)
+            hf, lf = ops.freq_split(o["fake_A"], 10, 8)
+        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2 (after pass 1)
+        _after(SB, ev_idt_B)
+        with torch.cuda.stream(SB):
+            _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                # A2B pass 3
+            _after(SB, ev_pred_A)
+            pred_A.record_stream(SB)
+            L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
+            L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
+                ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
+            root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
+            extra_B = self._extension_terms(o["recovered_B"], real_B)       # opt-in SSIM / wavelet-HF terms: one half per chain
+            for k, v in extra_B.items():
+                root = root + v
+        # ---- chain A, losses and backward
+        _after(SA, ev_pred_B)
+        pred_B.record_stream(SA)
+        with torch.cuda.stream(SA):
             L["loss_GAN_A2B"] = ops.mse_loss(pred_B, ones, w["beta4"])
             L["loss_cycle_ABA"] = ops.l1_loss(o["recovered_A"], real_A, w["beta3"]) + ops.bce_with_logits(o["hf_feature_A"], o["hf_feature_recovered_A"])
             chain_A = L["loss_GAN_A2B"] + L["loss_cycle_ABA"]
@@ -567,37 +533,19 @@ class TrainStep:
                 chain_A.backward()
             finally:
                 ops.wgrad_stream = None
-        _after(main, ev_b2a_2)
-        hf_feature_B, _, o["fake_A"] = G_B2A(hfB, lfB)                                      # B2A pass 3
-        o["hf_feature_B"] = hf_feature_B.detach()
-        pred_A, ev_pred_A = critic(self.netD_A, o["fake_A"], cA, main)
-        ev_idt_B, idt_B = identity(G_A2B, lfB, hfB, real_B, "idt_B", ev_a2b_1)              # A2B pass 2
-        hf, lf = ops.freq_split(o["fake_A"], 10, 8)
-        _after(main, ev_idt_B)
-        _, o["hf_feature_recovered_B"], o["recovered_B"] = G_A2B(lf, hf)                    # A2B pass 3
-        _after(main, ev_pred_A)
-        pred_A.record_stream(main)
-        L["loss_GAN_B2A"] = ops.mse_loss(pred_A, ones, w["beta5"])
-        L["loss_cycle_BAB"] = ops.l1_loss(o["recovered_B"], real_B, w["beta3"]) + \
-            ops.bce_with_logits(o["hf_feature_B"], o["hf_feature_recovered_B"], w["beta1"])
-        root = L["loss_GAN_B2A"] + L["loss_cycle_BAB"]
-        done = None
-        for k, v in self._extension_terms(o["recovered_B"], real_B).items():        # opt-in SSIM / wavelet-HF terms: one half per chain
-            root = root + v
-            extra_A[k].record_stream(main)
-            L[k] = v + extra_A[k].detach()
-            done = extra_A[k].detach() if done is None else done + extra_A[k].detach()
+        # ---- the caller's stream picks up the fakes (they feed the replay buffers and the discriminator phase) behind BOTH frozen
+        # discriminator passes: a discriminator's update phase runs on a branch stream ordered behind the caller only, and its
+        # BatchNorm running statistics must see the frozen pass first.  The loss scalars are read after the final joins.
+        for ev in (ev_a2b_1, ev_pred_B, ev_fake_A, ev_pred_A):
+            _after(main, ev)
         for k in ("loss_GAN_A2B", "loss_cycle_ABA"):
-            L[k].record_stream(main)
             L[k] = L[k].detach()
-        for k in ("fake_B", "hf_feature_A", "hf_feature_recovered_A", "recovered_A"):
-            o[k].record_stream(main)
-        L["loss_idt"] = idt_A + idt_B
+        for t in list(o.values()) + list(L.values()) + list(extra_A.values()) + list(extra_B.values()) + [root, pred_A, pred_B, idt_A, idt_B]:
+            t.record_stream(main)
         o["pred_fake_A"], o["pred_fake_B"] = pred_A, pred_B
-        L["loss_G"] = root.detach() + L["loss_GAN_A2B"] + L["loss_cycle_ABA"] + L["loss_idt"]
-        if done is not None:
-            L["loss_G"] = L["loss_G"] + done
-        self._chain_B_terms = None            # this arrangement has already formed every total on the caller's stream
+        # totals that mix the chains are formed by ``step`` after it has joined every stream
+        self._chain_B_terms = (root, (L["loss_GAN_A2B"], L["loss_cycle_ABA"], idt_A, idt_B),
+                               {k: (extra_A[k].detach(), v) for k, v in extra_B.items()})
         return o, L, root
 
     def _extension_terms(self, rec, real):
@@ -699,6 +647,8 @@ class TrainStep:
         # of the schedule cost more than the concurrency returns (batch 1 at 256^2: 41.8 vs 39.3 ms; batch 2: 48.3 vs 52.8)
         # ... a CAPTURED step has no host in its way: there the schedule pays at every size (batch 1: 29.9 against 35.4 ms per replay)
         capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            _guard.begin(torch.cuda.current_stream(self.device).cuda_stream)
         streams = self.overlap_wgrad and self._side is not None and (capturing or real_A.numel() >= self.overlap_min_pixels)
         set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
         self.opt_G.zero_grad()                                              # train.py:220 (before the first backward of a generator term)
@@ -706,11 +656,9 @@ class TrainStep:
         # another stream behind that launch by an event, so the schedule, and with it the order of the two gradient exchanges on the
         # communicator, depends on the batch shape alone, never on rank-local cache state)
         multi = streams
-        two_chains = multi and (self.capture_two_chains or not torch.cuda.is_current_stream_capturing())
-        if two_chains and self.eager_chain_A_forked and not torch.cuda.is_current_stream_capturing():
-            o, L, root = self._generators_two_chains_eager(real_A, real_B)
-        elif two_chains:
-            o, L, root = self._generators_two_chains(real_A, real_B)
+        two_chains = multi and (self.capture_two_chains or not capturing)
+        if two_chains:
+            o, L, root = self._generators_two_chains(real_A, real_B, chain_A_forked=self.eager_chain_A_forked and not capturing)
         else:
             o = self.forward_generators(real_A, real_B, self._branch if multi else None, (self._idt, self._side) if multi else None)
             # (2) generators, train.py:218-239
@@ -740,11 +688,16 @@ class TrainStep:
                     # there), the frozen discriminator passes' input gradients on the branch streams
                     _join(torch.cuda.current_stream(self.device), (self._idt, self._aba) + tuple(self._branch))
                 ops.join_wgrad_stream(side_G)
-            if two_chains and self._chain_B_terms is not None:     # chain B's terms were computed on its stream: the totals are formed after the join
-                root_B, rest, done, halves = self._chain_B_terms
-                L["loss_G"] = root_B.detach() + rest if done is None else root_B.detach() + rest + done
+            if two_chains:               # the chains' terms were computed on their streams: the totals are formed after the join
+                root_B, terms, halves = self._chain_B_terms
+                total = root_B.detach()
+                for t in terms:
+                    total = total + t
+                L["loss_idt"] = terms[2] + terms[3]
                 for k, (ha, hb) in halves.items():
                     L[k] = ha + hb.detach()
+                    total = total + ha
+                L["loss_G"] = total
                 self._chain_B_terms = None
             hyper_G = None if _static is None else _static["hyper_G"]
             g_update_aside = self.distributed and streams and self.overlap_exchange and side_G is not None
@@ -765,9 +718,12 @@ class TrainStep:
             if not early_D:
                 held = self._discriminator_phase(L, o, real_A, real_B, _static, branches, side_D)
         finally:
-            if streams:
-                self._join_discriminator_phase(branches, side_D)
-                ops.join_wgrad_stream(side_G)
+            try:
+                if streams:
+                    self._join_discriminator_phase(branches, side_D)
+                    ops.join_wgrad_stream(side_G)
+            finally:
+                _guard.end()
         del held
         if self.distributed and not d_reduced:
             self.opt_D.all_reduce(self.group, self.comm)
@@ -847,9 +803,11 @@ class GraphedTrainStep:
             self._static[k][1].fill_(ts.fake_A_buffer.max_size)
         pend = [m._pending_batches for m in self._bns]
         ops.invalidate_weight_cache()                                    # every first use inside the graph packs its weights
+        ops.reset_scale_arenas()                                         # f16x2: every absmax slot of the graph is zeroed inside the graph
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.losses = ts.step(self.real_A, self.real_B, _static=self._static)
+        ops.reset_scale_arenas()                                         # ... and eager code never draws slots from the graph's pool
         self._bn_delta = [m._pending_batches - p for m, p in zip(self._bns, pend)]
         for m, p in zip(self._bns, pend):                                # the capture pass executed nothing
             m._pending_batches = p

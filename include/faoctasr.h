@@ -46,7 +46,8 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
  * faoctasr_conv_wpack_floats(kind, C, M, KH, KW, stride, pad) floats (kind 0..3 in that order; C, M
  * as in the matching call) and `wpack_state`: 0 = none (flat im2col kernel), 1 = pack `w` into it
  * now, 2 = it already holds this `w` (valid until the weights change).
- * `precision`: 0 = exact fp32 on v_mfma_f32_32x32x2_f32; 2 = "bf16x3": operands split hi/lo into bf16, three
+ * `precision`: 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (Winograd F(2x2,3x3) on the dense stride-1 3x3 layers), 1 = the same
+ * without Winograd, 3 = "f16x2" (below: faoctasr_conv_set_scales); 2 = "bf16x3": operands split hi/lo into bf16, three
  * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (fp32-parity, ~5x the MFMA rate; needs a wpack buffer and
  * C >= 16, width >= 24 -- other shapes silently use the fp32 kernels).  The packed image depends on `precision` and on
  * whether the map is wide enough for the split kernel, so keep one buffer per (weights, precision, input size).
@@ -69,6 +70,23 @@ long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const flo
                             int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                             int reflect, int out_pad, int precision);
 int faoctasr_conv_pack_run(const void* jobs_dev, int njobs, long nblocks, faoctasr_stream_t stream);
+/* precision 3 ("f16x2") tables only, BEFORE faoctasr_conv_pack_run on the same stream: the absmax slot of every job's weight
+ * tensor (one block per job; the slot is the last word of the job's image).                                              */
+int faoctasr_conv_pack_scales(const void* jobs_dev, int njobs, faoctasr_stream_t stream);
+/* ---- precision 3, "f16x2": fp32-exact-class contraction at the 16-bit matrix-core rate ------------------------------
+ * Every fp32 operand is split into hi = f16(x s), lo = f16(x s - hi) (22 significant bits) and a product is accumulated in
+ * fp32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16; s is the power of two that puts the operand tensor's largest
+ * magnitude in [2^14, 2^15) and is divided out of the accumulators.  Measured against fp64 the result is at or below the
+ * error of the exact-f32 MFMA kernels (csrc/split16.h, profiles/r04_split_precision_error.log), at ~5x their rate.
+ * The largest magnitude of an ACTIVATION operand travels as its fp32 bit pattern in a caller-owned device word, the
+ * "absmax slot": zero the word, then faoctasr_absmax_bits(x, n, slot) (an atomicMax: several calls may fold several
+ * tensors into one slot).  The slots of the next convolution-type call of the calling thread are handed over with
+ * faoctasr_conv_set_scales(a, b): gather calls (conv2d_fwd / dgrad, conv_transpose2d_fwd / dgrad) read `a` = the slot of their
+ * gathered tensor (x, resp. dy); weight-gradient calls read `a` = slot of x and `b` = slot of dy.  The call consumes them
+ * (a precision-3 call without slots fails with FAOCTASR_EINVAL); the weights' own slot lives in the packed image.  Shapes
+ * the split kernels do not take (maps narrower than 24, fewer than 16 channels) silently run on the exact-f32 kernels. */
+int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream);
+int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b);
 /* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
  * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with
  * faoctasr_reflect_pad_bwd).                                                              */

@@ -550,6 +550,24 @@ def test_conv2d_winograd_split_k_small_grids(fa, shape):
         fa.ops.reproducible_forward = False
     assert torch.equal(r1, r2)
     assert rel_l2(r1, res[1][0]) < 5e-6
+    # with a fused activation the split cannot be used (atomics); the shape must STAY on the Winograd kernel (unsplit) --
+    # a PackPlan records its image without the activation, and another route would read that image as a patch image
+    wd = w.clone().requires_grad_(True)
+    with torch.no_grad():
+        direct = F.leaky_relu(F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1), 0.2)
+        fa.ops.clear_touched()
+        first = fa.ops.conv2d(x, wd, b, 1, 1, False, "lrelu", 0.2)               # packs inline (state 1)
+        assert fa._lib.load().faoctasr_last_route() == routes[0]
+        plan = fa.ops.PackPlan([wd], 0)
+        assert plan.njobs == 1
+        for e in fa.ops._wpack_cache.values():
+            if e.wref() is wd:
+                e.buf.zero_()
+        assert plan.run()
+        planned = fa.ops.conv2d(x, wd, b, 1, 1, False, "lrelu", 0.2)             # state 2: the image the plan packed
+        assert fa._lib.load().faoctasr_last_route() == routes[0]
+    assert rel_l2(first, direct) < 5e-6
+    assert torch.equal(first, planned)
 
 
 SPLIT_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] // c[6] >= 24]
@@ -647,6 +665,108 @@ def test_conv_transpose2d_bf16x3(fa, case):
     x3 = s == 2 and k in (3, 4) and p == 1 and C % 64 == 0 and M % 64 == 0 and W % 32 == 0 and H % 2 == 0 and ref.shape[-1] == 2 * W and ref.shape[-2] == 2 * H
     assert (fa._lib.load().faoctasr_last_route() == 15) == x3, case
     assert rel_l2(dwd, wr.grad) < 3e-5
+
+
+def _conv_f64(x, w, b, s, p, reflect, cot):
+    """fp64 CPU convolution with its input / weight gradients: what both arithmetics are measured against."""
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    xin = F.pad(xr, (p, p, p, p), mode="reflect") if reflect else xr
+    ref = F.conv2d(xin, wr, None if b is None else b.double(), stride=s, padding=0 if reflect else p)
+    ref.backward(cot.double())
+    return ref.detach(), xr.grad, wr.grad
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv2d_f16x2(fa, case):
+    """precision 3 ("f16x2": operands scaled by a power of two and split hi/lo into fp16, 3 f16 MFMAs per product, csrc/split16.h):
+    forward, input gradient and weight gradient, each measured against an fp64 convolution BESIDE the exact-f32 kernels (direct
+    form, no Winograd) on the same data.  The claim the headline rests on: the split contraction is in the exact-f32 kernels' error
+    class -- measured 0.7x .. 1.4x of their error per layer and operand (profiles/r04_f16x2_layer_errors.txt; the f32 kernels
+    split their reduction over chunks and blocks, which is worth about as much as the split's 3-per-16 accumulator roundings), both
+    2e-7 .. 1e-6 against fp64 and ~15x below bf16x3.  The cotangent is ~1e-4 with a heavy tail, like a real gradient: without
+    the per-tensor scale its lo halves would be fp16 subnormals."""
+    N, C, H, W, M, k, s, p, reflect, bias, act = case
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(M, C, k, k, generator=g) * 0.05
+    b = torch.randn(M, generator=g) if bias else None
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    cot = 1e-4 * torch.randn(N, M, OH, OW, generator=g) * torch.exp(1.5 * torch.randn(N, M, OH, OW, generator=g))
+    ref, dx64, dw64 = _conv_f64(x, w, b, s, p, reflect, cot)
+    err = {}
+    for prec in (1, 3):
+        fa.ops.conv_precision = prec
+        try:
+            xd, wd = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+            out = fa.ops.conv2d(xd, wd, dev(b) if bias else None, s, p, reflect, None, 0.2)
+            out.backward(dev(cot))
+            torch.cuda.synchronize()
+        finally:
+            fa.ops.conv_precision = 0
+        err[prec] = (rel_l2(out, ref), rel_l2(xd.grad, dx64), rel_l2(wd.grad, dw64))
+    for what, e32, e16 in zip(("y", "dx", "dw"), err[1], err[3]):
+        print("f16x2-vs-f32 %s %s f32 %.3e f16x2 %.3e ratio %.2f" % (case, what, e32, e16, e16 / e32))
+        assert e16 <= 1.6 * e32 + 5e-8, (case, what, e32, e16)
+        assert e16 < 2e-6, (case, what, e16)
+    # the forward really ran on the split kernel (the route is per calling thread: ask the C ABI directly)
+    from faoctasr._lib import call, ptr, stream_ptr
+    fa.ops.conv_precision = 3
+    try:
+        with torch.no_grad():
+            fa.ops.conv2d(dev(x), dev(w), None, s, p, reflect, None, 0.2)
+        assert fa._lib.load().faoctasr_last_route() == (5 if M == 1 else 4), case      # (the 64 -> 1 head is a VALU kernel in every mode)
+    finally:
+        fa.ops.conv_precision = 0
+
+
+def test_f16x2_needs_slots_and_scales_any_range(fa):
+    """(a) A precision-3 call without absmax slots fails loudly; (b) the result does not depend on the operands' magnitude: the
+    same convolution on x * 2^-30 and w * 2^20 (fp16 could represent neither) equals the unscaled one times 2^-10, bit for bit,
+    because the scales are powers of two."""
+    from faoctasr._lib import KernelError, call, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 24, 64, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.05
+    fa.ops.conv_precision = 3
+    try:
+        with torch.no_grad():
+            y0 = fa.ops.conv2d(dev(x), dev(w), None, 1, 1, False, None, 0.2)
+            y1 = fa.ops.conv2d(dev(x * 2.0 ** -30), dev(w * 2.0 ** 20), None, 1, 1, False, None, 0.2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0 * 2.0 ** -10)
+        xd, wd, yd = dev(x), dev(w), torch.empty_like(y0)
+        n = fa._lib.load().faoctasr_conv_wpack_floats(0, 32, 64, 3, 3, 1, 1, 3)
+        wp = torch.empty(n, device="cuda")
+        with pytest.raises(KernelError, match="absmax"):
+            call("conv2d_fwd", ptr(xd), ptr(wd), None, ptr(yd), 2, 32, 24, 64, 64, 3, 3, 1, 1, 0, 0, 0.2, ptr(wp), 1, 3, stream_ptr())
+    finally:
+        fa.ops.conv_precision = 0
+
+
+@pytest.mark.parametrize("case", [c for c in CONVT_CASES if c[1] >= 16 and c[3] >= 24])
+def test_conv_transpose2d_f16x2(fa, case):
+    N, C, H, W, M, k, s, p, op, bias = case
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, M, k, k, generator=g) * 0.05
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, stride=s, padding=p, output_padding=op)
+    cot = 1e-4 * torch.randn(ref.shape, generator=g) * torch.exp(1.5 * torch.randn(ref.shape, generator=g))
+    ref.backward(cot.double())
+    err = {}
+    for prec in (1, 3):
+        fa.ops.conv_precision = prec
+        try:
+            xd, wd = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+            out = fa.ops.conv_transpose2d(xd, wd, None, s, p, op)
+            out.backward(dev(cot))
+            torch.cuda.synchronize()
+        finally:
+            fa.ops.conv_precision = 0
+        err[prec] = (rel_l2(out, ref), rel_l2(xd.grad, xr.grad), rel_l2(wd.grad, wr.grad))
+    for what, e32, e16 in zip(("y", "dx", "dw"), err[1], err[3]):
+        print("f16x2-vs-f32 convT %s %s f32 %.3e f16x2 %.3e ratio %.2f" % (case, what, e32, e16, e16 / e32))
+        assert e16 <= 1.6 * e32 + 5e-8, (case, what, e32, e16)
 
 
 def test_input_pipeline_vs_oracle(fa, O):
@@ -766,7 +886,7 @@ def test_eval_metrics_vs_oracle_and_closed_forms(fa, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_batched_weight_pack_equals_per_layer_pack(fa, precision):
     """faoctasr_conv_pack_job / faoctasr_conv_pack_run (csrc/conv_pack.hip): one launch writes, bit for bit, the packed-weight
     images that the gather calls write themselves with wpack_state 1 -- for every route that keeps an image (LDS-patch incl.

@@ -263,6 +263,70 @@ def test_train_step_bf16x3_precision(fa, O, cfg):
     assert fa.ops.conv_precision == 0          # the mode is scoped to the step
 
 
+@pytest.mark.parametrize("cfg", [2, 0, 1])
+def test_train_step_f16x2_precision(fa, O, cfg):
+    """precision "f16x2" (every wide-map convolution's three GEMMs on fp16 hi/lo-split, power-of-two-scaled operands; per-layer
+    error at or below the exact-f32 kernels': test_conv2d_f16x2): the step meets the SAME bars against the REFERENCE fixtures as
+    the exact-f32 step (test_train_step_vs_golden) -- step-0 losses 1e-3, gradient norms 2e-3 -- on all three fixture configs,
+    over all their steps for the losses."""
+    with open(os.path.join(GOLD, "golden_step.json")) as f:
+        gold = json.load(f)["configs"][cfg]
+    random.seed(1234)
+    n = build_nets(fa, O)
+    ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], precision="f16x2")
+    for s, gs in enumerate(gold["steps"]):
+        a, b = O.synthetic_batch(gold["B"], gold["H"], seed=1234 + 17 * s)
+        L = ts.step(a.cuda(), b.cuda(), sync=True)
+        _check_step(L, gs, s)
+        if s == 0:
+            gn = ts.grad_norms()
+            for k in gn:
+                assert gn[k] == pytest.approx(gs["grad_norm"][k], rel=2e-3), (k, gn[k])
+    assert fa.ops.conv_precision == 0          # the mode is scoped to the step
+
+
+def test_step_gradients_vs_fp64_oracle_f16x2_beside_f32(fa, O):
+    """What the f16x2 arithmetic does to the WHOLE step, measured against an fp64 run of the oracle (192^2, batch 2, step 0: the
+    reference's algorithm in double precision, same weights and data): the relative L2 error of each network's full gradient (every
+    live parameter, matched by state_dict name) and the losses, for the exact-f32 step and for the f16x2 step.  The split
+    contraction must not cost accuracy: each of its errors is held to 1.5x the exact-f32 step's (+ 1e-6; both steps' gradients end
+    in fp32 atomics whose order varies from run to run), and both to the parity bars (losses 1e-3, here < 1e-4).  The numbers of one
+    run are kept in profiles/r04_step_error_vs_fp64.txt."""
+    random.seed(1234)
+    a, b = O.synthetic_batch(2, 192, seed=1234)
+    torch.set_num_threads(host_threads())
+    S = O.StepOracle(seed=0, dtype=torch.float64)
+    L64 = S.train_step(a, b)
+    g64 = {k: {name: S.state[k][name].grad for name in S.state[k] if getattr(S.state[k][name], "grad", None) is not None} for k in S.state}
+    err = {}
+    for prec in ("f32", "f16x2"):
+        random.seed(1234)
+        n = build_nets(fa, O)
+        ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], precision=prec)
+        L = ts.step(a.cuda(), b.cuda(), sync=True)
+        torch.cuda.synchronize()
+        e = {}
+        for k, net in n.items():
+            num = den = 0.0
+            for name, p in fa.live_parameters(net):
+                ref = g64[k][name]
+                d = p.grad.detach().cpu().double() - ref
+                num += float((d * d).sum())
+                den += float((ref * ref).sum())
+            e["grad_" + k] = (num / den) ** 0.5
+        for key in L64:
+            e[key] = abs(L[key] - L64[key]) / max(abs(L64[key]), 1e-12)
+        err[prec] = e
+    for key in sorted(err["f32"]):
+        print("step-vs-fp64 %-18s f32 %.3e   f16x2 %.3e" % (key, err["f32"][key], err["f16x2"][key]))
+    for key, e32 in err["f32"].items():
+        e16 = err["f16x2"][key]
+        if key.startswith("grad_"):
+            assert e16 <= 1.5 * e32 + 1e-6, (key, e32, e16)
+        else:
+            assert e16 < 1e-4 and e32 < 1e-4, (key, e32, e16)
+
+
 def test_graph_captured_step_matches_eager_and_golden(fa, O):
     """SURVEY 8f-1 / BASELINE config 5: the whole step as one captured hipGraph (device-side replay buffer, AdamW scalars in device
     memory).  Same seeds -> the graph's losses follow the eager step and the reference fixture; capturing does not advance the

@@ -228,3 +228,51 @@ def test_winograd_error_budget_f2x2_vs_f4x4():
         ref = F.conv2d(x.double(), w.double(), padding=1)
         err = {m: float((wino(x, w, m).double() - ref).norm() / ref.norm()) for m in (2, 4)}
         assert err[2] < b2 and err[4] < b4 and err[4] > err[2], (C, err)
+
+
+def test_capture_guard_refuses_a_cycle_of_forked_waits():
+    """ROCm 7.2's hipStreamEndCapture crashes (SIGSEGV, unbounded recursion) when two FORKED capture streams
+    wait on each other.  ``train._CaptureGuard`` keeps the forked -> forked wait edges of an open capture and
+    turns the wait that would close a cycle into a KernelError; waits to and from the origin stream, and everything outside a
+    capture, pass.  Exercised through the schedule's own helpers (``_wait`` / ``_after`` / ``_join``) on stand-in streams."""
+    from faoctasr import train
+
+    class FakeStream:
+        def __init__(self, sid):
+            self.cuda_stream, self.waits = sid, []
+
+        def wait_stream(self, other):
+            self.waits.append(other.cuda_stream)
+
+        def wait_event(self, ev):
+            self.waits.append(("event", ev))
+
+        def record_event(self):
+            return "ev%d" % self.cuda_stream
+
+    origin, idt, aba, side = (FakeStream(i) for i in (1, 2, 3, 4))
+    g = train._guard
+    # outside a capture nothing is recorded or refused: round 2's eager arrangement (idt <-> aba wait on each other) is legal
+    train._wait(idt, aba)
+    train._wait(aba, idt)
+    assert g.edges == {} and idt.waits == [3] and aba.waits == [2]
+    g.begin(origin.cuda_stream)
+    try:
+        train._wait(idt, origin)                       # to / from the origin: never listed
+        train._wait(origin, idt)
+        train._wait(idt, idt)                          # a stream never waits on itself
+        assert g.edges == {}
+        train._after(aba, train._Mark(idt))            # the captured schedule: aba waits on idt, side on everybody
+        train._join(side, (idt, aba, origin))
+        assert g.edges == {3: {2}, 4: {2, 3}}
+        with pytest.raises(faoctasr.KernelError, match="cycle of waits"):
+            train._after(idt, train._Mark(aba))        # ... and idt on aba would close idt -> aba -> idt
+        with pytest.raises(faoctasr.KernelError, match="cycle of waits"):
+            train._wait(idt, side)                     # a longer cycle: idt -> side -> aba -> idt
+        assert ("event", "ev3") not in idt.waits and 4 not in idt.waits      # the refused waits were not issued
+        faoctasr.ops.wait_guard(side.cuda_stream, aba.cuda_stream)           # ops' weight-gradient stream reports to the same guard
+        with pytest.raises(faoctasr.KernelError):
+            faoctasr.ops.wait_guard(aba.cuda_stream, side.cuda_stream)
+    finally:
+        g.end()
+    assert g.origin is None and g.edges == {}
