@@ -22,6 +22,7 @@ _SIG = {
     "conv_pack_scales": (_I, "p i p"),
     "absmax_bits": (_I, "p l p p"),
     "conv_set_scales": (_I, "pp"),
+    "out_absmax": (_I, "p"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
     "conv2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),

@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const char* __rest
     }
 }
 
-// f16x2 images: the weights' absmax slots, one block per job, before the images are packed (pack_bodies.h, split16.h)
+// f16x2 images: the weights' absmax slots, SPLIT_WPARTS blocks per job, before the images are packed (pack_bodies.h, split16.h)
 __global__ __launch_bounds__(256) void conv_pack_absmax_kernel(const char* __restrict__ jobs, int njobs) {
     __shared__ unsigned red[4];
-    const PackJob& J = *reinterpret_cast<const PackJob*>(jobs + (size_t)blockIdx.x * PACK_JOB_BYTES);
-    if (J.type == PACK_SPLIT && J.g.split.f16) split_absmax_block(J.w, J.wp, J.g.split, red);
+    const PackJob& J = *reinterpret_cast<const PackJob*>(jobs + (size_t)(blockIdx.x / SPLIT_WPARTS) * PACK_JOB_BYTES);
+    if (J.type == PACK_SPLIT && J.g.split.f16) split_absmax_block(J.w, J.wp, J.g.split, (int)(blockIdx.x % SPLIT_WPARTS), red);
 }
 
 }  // namespace faoctasr
@@ -48,7 +48,7 @@ extern "C" {
 int faoctasr_conv_pack_scales(const void* jobs_dev, int njobs, faoctasr_stream_t stream) {
     if (njobs == 0) return FAOCTASR_OK;
     if (!jobs_dev || njobs < 0) return fail(FAOCTASR_EINVAL, "conv_pack_scales: bad job table");
-    hipLaunchKernelGGL(conv_pack_absmax_kernel, dim3((unsigned)njobs), dim3(256), 0, (hipStream_t)stream, (const char*)jobs_dev, njobs);
+    hipLaunchKernelGGL(conv_pack_absmax_kernel, dim3((unsigned)njobs * SPLIT_WPARTS), dim3(256), 0, (hipStream_t)stream, (const char*)jobs_dev, njobs);
     return check_launch("conv_pack_absmax");
 }
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void split_absmax_kernel(const float* __restrict__ w, float* __restrict__ wp, const SplitGeom g) {
     __shared__ unsigned red[4];
-    split_absmax_block(w, wp, g, red);
+    split_absmax_block(w, wp, g, (int)blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         const unsigned cstep = 4u * (unsigned)chw;
         const float* xin = x;
         float sx = 1.f;                                                  // f16x2: the activation tensor's scale (wave-uniform)
-        if constexpr (F16) sx = f16x2_scale(*x_slot);
+        if constexpr (F16) sx = f16x2_scale(absmax_read(x_slot));
         // ---- single-pixel items (all of the patch when !QUAD)
         constexpr int NSI = QUAD ? 2 : NPI;
         unsigned poff[NSI];
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             tile_coords(tile, cn, cty, ctx);
             const int mrow0 = m0 + 4 * lh;
             if constexpr (F16) {                                         // the operands were x * s_x and w * s_w
-                const float inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*w_slot);
+                const float inv = f16x2_inv_scale(absmax_read(x_slot)) * f16x2_inv_scale(split_w_absmax(w_slot));
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -835,7 +835,7 @@ int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t
     const long total = g.pack_off[4];
     if (total <= 0) return FAOCTASR_OK;
     if (g.f16) {
-        hipLaunchKernelGGL(split_absmax_kernel, dim3(1), dim3(256), 0, s, w, wp, g);
+        hipLaunchKernelGGL(split_absmax_kernel, dim3(SPLIT_WPARTS), dim3(256), 0, s, w, wp, g);
         hipLaunchKernelGGL(split_pack_kernel<true>, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), g);
     } else {
         hipLaunchKernelGGL(split_pack_kernel<false>, dim3((unsigned)pack_job_blocks(total / (8L * g.Mpad))), dim3(256), 0, s, w, reinterpret_cast<unsigned short*>(wp), g);

@@ -57,8 +57,16 @@ struct SplitGeom {
     long w_elems;                  // extent of the weight tensor (its absmax is taken over all of it)
     int taps[64];                  // (oy-oy0) | (ox-ox0)<<8 | widx<<16
 };
-// float index of the weights' absmax slot inside a split-precision packed image (split_pack_floats() - 1)
-inline __host__ __device__ long split_scale_slot(const SplitGeom& g) { return g.plane_stride + 511; }
+// float index of the weights' absmax slots inside a split-precision packed image: SPLIT_WPARTS partial maxima (one per block of the
+// absmax pass, plain stores: nothing to zero, no atomics), whose maximum every reader takes (split_w_absmax)
+constexpr int SPLIT_WPARTS = 8;
+inline __host__ __device__ long split_scale_slot(const SplitGeom& g) { return g.plane_stride + 504; }
+__device__ __forceinline__ unsigned split_w_absmax(const unsigned* slots) {
+    unsigned m = slots[0];
+#pragma unroll
+    for (int i = 1; i < SPLIT_WPARTS; ++i) m = slots[i] > m ? slots[i] : m;
+    return m;
+}
 
 // One weight-packing job of a batched launch (conv_pack.hip; include/faoctasr.h FAOCTASR_PACK_JOB_BYTES).  A job is what a
 // wpack_state == 1 call would have launched by itself: the same geometry, the same element order.

@@ -15,6 +15,7 @@
 // Backward of "BN + ReLU/LeakyReLU" without a residual takes the activation mask from x (y = act(x*g + b) is recomputed with
 // the forward's own expression), so the saved output y is not read (y == NULL): 4 of the 16 bytes per element of that call.
 #include "common.h"
+#include "split16.h"
 
 namespace faoctasr {
 
@@ -36,6 +37,14 @@ __device__ __forceinline__ void for_row_pieces(int R, int HW, int r, long e0, lo
         const long hi = (e1 < pb + HW ? e1 : pb + HW) - pb;
         f(((long)n * R + r) * HW, lo, hi);
     }
+}
+
+// f16x2 (split16.h): the largest |output| of a kernel, folded into the caller's absmax slot (faoctasr_out_absmax) -- one atomicMax
+// per block on the fp32 bit pattern; fmaxf drops NaNs, so a NaN never becomes the scale
+__device__ __forceinline__ float amax4(float m, const float4& v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ void amax_publish(float m, unsigned* __restrict__ slot) {
+    __shared__ unsigned amax_red[4];
+    absmax_publish_block(__builtin_bit_cast(unsigned, m), slot, amax_red);      // m >= 0: its bits order like the value
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -122,9 +131,10 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          float* __restrict__ y, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, const float* __restrict__ ws, int R, int Cg, int HW, long L,
-                                                         int S, float eps, float momentum, int act, float slope, long per) {
+                                                         int S, float eps, float momentum, int act, float slope, long per,
+                                                         unsigned* __restrict__ amax) {
     const int r = blockIdx.y;
-    float a = 0.f, q = 0.f;
+    float a = 0.f, q = 0.f, mx = 0.f;
     for (int s = 0; s < S; ++s) {   // fixed order: deterministic
         a += ws[((long)r * S + s) * 2 + 0];
         q += ws[((long)r * S + s) * 2 + 1];
@@ -154,9 +164,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                 o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
                 o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
                 st4(y + base + i + 1024L * u, o);
+                mx = amax4(mx, o);
             }
         }
     });
+    if (amax) amax_publish(mx, amax);
 }
 
 // backward reduce: s1 = sum dy', s2 = sum dy' * xhat, dy' = dy * act'(y);  y == NULL: mask from the recomputed pre-activation
@@ -214,9 +226,9 @@ __global__ __launch_bounds__(256, 8) void norm_bwd_dx_kernel(const float* __rest
                                                           const float* __restrict__ save_invstd, float* __restrict__ dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dres,
                                                           const float* __restrict__ ws, int R, int Cg, int HW, long L, int S, int act,
-                                                          float slope, long per, int accumulate_affine) {
+                                                          float slope, long per, int accumulate_affine, unsigned* __restrict__ amax) {
     const int r = blockIdx.y;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
     for (int s = 0; s < S; ++s) {
         s1 += ws[((long)r * S + s) * 2 + 0];
         s2 += ws[((long)r * S + s) * 2 + 1];
@@ -262,9 +274,11 @@ __global__ __launch_bounds__(256, 8) void norm_bwd_dx_kernel(const float* __rest
                 d.z = gi * (g[u].z - m1 - (xv[u].z - mean) * invstd * m2);
                 d.w = gi * (g[u].w - m1 - (xv[u].w - mean) * invstd * m2);
                 st4(dx + o, d);
+                mx = amax4(mx, d);
             }
         }
     });
+    if (amax) amax_publish(mx, amax);
 }
 
 // ---- small rows: the whole row of a block in registers, one kernel per direction -----------------------------------------------
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256) void norm_fwd_small_kernel(const float* __rest
                                                              const float* __restrict__ beta, const float* __restrict__ res, float* __restrict__ y,
                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                              float* __restrict__ rmean, float* __restrict__ rvar, int R, int Cg, int HW, long L,
-                                                             float eps, float momentum, int act, float slope) {
+                                                             float eps, float momentum, int act, float slope, unsigned* __restrict__ amax) {
     __shared__ float red[4];
     const int r = blockIdx.x;
     long off[K];
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(256) void norm_fwd_small_kernel(const float* __rest
     const int cg = r % Cg;
     const float gsc = (gamma ? gamma[cg] : 1.f) * st.invstd;
     const float bsh = (beta ? beta[cg] : 0.f) - st.mean * gsc;
+    float mx = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!ok[k]) continue;
@@ -325,7 +340,9 @@ __global__ __launch_bounds__(256) void norm_fwd_small_kernel(const float* __rest
         o.x = act_apply(o.x, act, slope); o.y = act_apply(o.y, act, slope);
         o.z = act_apply(o.z, act, slope); o.w = act_apply(o.w, act, slope);
         st4(y + off[k], o);
+        mx = amax4(mx, o);
     }
+    if (amax) amax_publish(mx, amax);
 }
 
 template <int K>
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const float* __rest
                                                              const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                              float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ dres, int R, int Cg, int HW, long L, int act, float slope,
-                                                             int accumulate_affine) {
+                                                             int accumulate_affine, unsigned* __restrict__ amax) {
     __shared__ float red[4];
     const int r = blockIdx.x;
     long off[K];
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const float* __rest
     }
     const float gi = gm * invstd;
     const float m1 = s1 / (float)L, m2 = s2 / (float)L;
+    float mx = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!ok[k]) continue;
@@ -388,7 +406,9 @@ __global__ __launch_bounds__(256) void norm_bwd_small_kernel(const float* __rest
         d.z = gi * (g[k].z - m1 - (xv[k].z - mean) * invstd * m2);
         d.w = gi * (g[k].w - m1 - (xv[k].w - mean) * invstd * m2);
         st4(dx + off[k], d);
+        mx = amax4(mx, d);
     }
+    if (amax) amax_publish(mx, amax);
 }
 
 // ---- generic scalar kernels (HW % 4 != 0) ----------------------------------------------------------------------------------------
@@ -528,14 +548,14 @@ static void norm_split(long L, int R, int& S, long& per) {
 
 static int norm_fwd(const float* x, const float* gamma, const float* beta, const float* res, float* y, float* save_mean,
                     float* save_invstd, float* rmean, float* rvar, int NI, int R, int Cg, int HW, float eps, float momentum,
-                    int act, float slope, float* ws, hipStream_t st) {
+                    int act, float slope, float* ws, hipStream_t st, unsigned* amax) {
     if (!x || !y || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_fwd: null pointer");
     if (NI <= 0 || R <= 0 || HW <= 0) return fail(FAOCTASR_EINVAL, "norm_fwd: bad shape");
     const long L = (long)NI * HW;
     if ((HW & 3) == 0 && L <= BN_SMALL_FWD) {
         auto go = [&](auto k) {
             hipLaunchKernelGGL(k, dim3(R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar, R, Cg, HW, L, eps,
-                               momentum, act, slope);
+                               momentum, act, slope, amax);
         };
         if (L <= 4096) go(norm_fwd_small_kernel<4>);
         else if (L <= 8192) go(norm_fwd_small_kernel<8>);
@@ -547,8 +567,9 @@ static int norm_fwd(const float* x, const float* gamma, const float* beta, const
     if ((HW & 3) == 0) {
         hipLaunchKernelGGL(norm_stats_kernel, dim3(S, R), dim3(256), 0, st, x, ws, R, HW, L, S, per);
         hipLaunchKernelGGL(norm_apply_kernel, dim3(S, R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar, ws, R,
-                           Cg, HW, L, S, eps, momentum, act, slope, per);
+                           Cg, HW, L, S, eps, momentum, act, slope, per, amax);
     } else {
+        if (amax) return fail(FAOCTASR_EUNSUPPORTED, "norm_fwd: faoctasr_out_absmax needs a map size that is a multiple of 4");
         hipLaunchKernelGGL(norm_stats_generic_kernel, dim3(S, R), dim3(256), 0, st, x, ws, R, HW, L, S, per);
         hipLaunchKernelGGL(norm_apply_generic_kernel, dim3(S, R), dim3(256), 0, st, x, gamma, beta, res, y, save_mean, save_invstd, rmean, rvar,
                            ws, R, Cg, HW, L, S, eps, momentum, act, slope, per);
@@ -558,8 +579,9 @@ static int norm_fwd(const float* x, const float* gamma, const float* beta, const
 
 static int norm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta, const float* save_mean,
                     const float* save_invstd, float* dx, float* dgamma, float* dbeta, float* dres, int NI, int R, int Cg, int HW,
-                    int act, float slope, int accumulate_affine, float* ws, hipStream_t st) {
+                    int act, float slope, int accumulate_affine, float* ws, hipStream_t st, unsigned* amax) {
     if (!x || !dy || !dx || !save_mean || !save_invstd || !ws) return fail(FAOCTASR_EINVAL, "norm_bwd: null pointer");
+    if (amax && (HW & 3)) return fail(FAOCTASR_EUNSUPPORTED, "norm_bwd: faoctasr_out_absmax needs a map size that is a multiple of 4");
     if (act == FAOCTASR_ACT_TANH && !y) return fail(FAOCTASR_EINVAL, "norm_bwd: the tanh derivative needs the forward output");
     const long L = (long)NI * HW;
     const int accumulate = (Cg != R) || accumulate_affine;
@@ -570,7 +592,7 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
     if ((HW & 3) == 0 && L <= BN_SMALL_BWD) {
         auto go = [&](auto k) {
             hipLaunchKernelGGL(k, dim3(R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, dres, R, Cg, HW, L,
-                               act, slope, accumulate);
+                               act, slope, accumulate, amax);
         };
         if (L <= 4096) go(norm_bwd_small_kernel<4>);
         else go(norm_bwd_small_kernel<8>);
@@ -582,7 +604,7 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
         auto go = [&](auto kr, auto kd) {
             hipLaunchKernelGGL(kr, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, ws, R, Cg, HW, L, S, act, slope, per);
             hipLaunchKernelGGL(kd, dim3(S, R), dim3(256), 0, st, x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, dres, ws, R, Cg,
-                               HW, L, S, act, slope, per, accumulate);
+                               HW, L, S, act, slope, per, accumulate, amax);
         };
         if (y && act != FAOCTASR_ACT_NONE) go(norm_bwd_reduce_kernel<true, 2>, norm_bwd_dx_kernel<true, 2>);
         else go(norm_bwd_reduce_kernel<false, BN_NU>, norm_bwd_dx_kernel<false, BN_NU>);
@@ -599,7 +621,20 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
 
 using namespace faoctasr;
 
+// the absmax slot faoctasr_out_absmax left for this thread's next BatchNorm call: taken (and cleared) by that call
+static thread_local unsigned* g_out_absmax = nullptr;
+static unsigned* take_out_absmax() {
+    unsigned* p = g_out_absmax;
+    g_out_absmax = nullptr;
+    return p;
+}
+
 extern "C" {
+
+int faoctasr_out_absmax(unsigned* slot) {
+    g_out_absmax = slot;
+    return FAOCTASR_OK;
+}
 
 long faoctasr_bn_workspace_floats(int C) { return (long)C * BN_MAX_SPLIT * 2; }
 
@@ -607,7 +642,7 @@ int faoctasr_batchnorm_train_fwd(const float* x, const float* gamma, const float
                                  float* save_mean, float* save_invstd, float* running_mean, float* running_var, int N, int C,
                                  int HW, float eps, float momentum, int act, float slope, float* workspace, faoctasr_stream_t stream) {
     return norm_fwd(x, gamma, beta, residual, y, save_mean, save_invstd, running_mean, running_var, N, C, C, HW, eps, momentum, act,
-                    slope, workspace, (hipStream_t)stream);
+                    slope, workspace, (hipStream_t)stream, take_out_absmax());
 }
 
 int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
@@ -615,21 +650,21 @@ int faoctasr_batchnorm_train_bwd(const float* x, const float* dy, const float* y
                                  int N, int C, int HW, int act, float slope, int accumulate_affine, float* workspace,
                                  faoctasr_stream_t stream) {
     return norm_bwd(x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, dres, N, C, C, HW, act, slope, accumulate_affine,
-                    workspace, (hipStream_t)stream);
+                    workspace, (hipStream_t)stream, take_out_absmax());
 }
 
 // InstanceNorm2d = the same kernels over R = N*C rows of one image each (workspace: faoctasr_bn_workspace_floats(N*C))
 int faoctasr_instancenorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
                               int N, int C, int HW, float eps, int act, float slope, float* workspace, faoctasr_stream_t stream) {
     return norm_fwd(x, gamma, beta, nullptr, y, save_mean, save_invstd, nullptr, nullptr, 1, N * C, C, HW, eps, 0.f, act, slope,
-                    workspace, (hipStream_t)stream);
+                    workspace, (hipStream_t)stream, nullptr);
 }
 
 int faoctasr_instancenorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                               const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, int HW,
                               int act, float slope, float* workspace, faoctasr_stream_t stream) {
     return norm_bwd(x, dy, y, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, nullptr, 1, N * C, C, HW, act, slope, 0, workspace,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"

@@ -78,7 +78,7 @@ __device__ __forceinline__ void split_pack_block(const float* __restrict__ w, un
     const long rowlen = 8L * g.Mpad;
     const long nrows = g.pack_off[4] / rowlen;
     float sc = 1.f;
-    if constexpr (F16) sc = f16x2_scale(reinterpret_cast<const unsigned*>(wp)[split_scale_slot(g)]);
+    if constexpr (F16) sc = f16x2_scale(split_w_absmax(reinterpret_cast<const unsigned*>(wp) + split_scale_slot(g)));
     for (long row = lb; row < nrows; row += nb) {
         int ph = 0;
         while (ph + 1 < g.nphase && row * rowlen >= g.pack_off[ph + 1]) ++ph;
@@ -101,11 +101,24 @@ __device__ __forceinline__ void split_pack_block(const float* __restrict__ w, un
     }
 }
 
-// the largest |w| of a weight tensor, as its fp32 bit pattern, into the f16x2 image's slot: ONE block per tensor (a layer that takes
-// this route has at most 256 x 256 x 9 weights), so the slot is written once, plainly -- nothing to zero, no atomics
-__device__ __forceinline__ void split_absmax_block(const float* __restrict__ w, float* __restrict__ wp, const SplitGeom& g, unsigned* red /* LDS, 4 words */) {
+// the largest |w| of a weight tensor, as fp32 bit patterns, into the f16x2 image's slots: block `part` of SPLIT_WPARTS takes every
+// SPLIT_WPARTS-th 16-byte piece and stores ITS maximum to slot `part` -- plain stores, nothing to zero, no atomics; readers take the
+// maximum of the slots (split_w_absmax).  A layer on this route has at most 256 x 256 x 9 weights (2.4 MB).
+__device__ __forceinline__ void split_absmax_block(const float* __restrict__ w, float* __restrict__ wp, const SplitGeom& g, int part, unsigned* red /* LDS, 4 words */) {
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
     unsigned mx = 0;
-    for (long i = threadIdx.x; i < g.w_elems; i += 256) {
+    const bool vec = (reinterpret_cast<unsigned long>(w) & 15) == 0;
+    const long n4 = vec ? g.w_elems >> 2 : 0;
+    const u32x4v* w4 = reinterpret_cast<const u32x4v*>(w);
+    for (long i = (long)part * 256 + threadIdx.x; i < n4; i += 256L * SPLIT_WPARTS) {
+        const u32x4v v = w4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned b = v[j] & 0x7fffffffu;
+            mx = b > mx ? b : mx;
+        }
+    }
+    for (long i = (n4 << 2) + (long)part * 256 + threadIdx.x; i < g.w_elems; i += 256L * SPLIT_WPARTS) {
         const unsigned b = __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu;
         mx = b > mx ? b : mx;
     }
@@ -119,7 +132,7 @@ __device__ __forceinline__ void split_absmax_block(const float* __restrict__ w, 
     if (threadIdx.x == 0) {
         unsigned m = red[0];
         for (int i = 1; i < 4; ++i) m = red[i] > m ? red[i] : m;
-        reinterpret_cast<unsigned*>(wp)[split_scale_slot(g)] = m;
+        reinterpret_cast<unsigned*>(wp)[split_scale_slot(g) + part] = m;
     }
 }
 

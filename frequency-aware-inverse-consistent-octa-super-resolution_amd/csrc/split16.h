@@ -5,12 +5,18 @@
 //   f16x2  (F16 = true) : hi = f16(x s), lo = f16(x s - hi); 22 significant bits, and fp16's 5-bit exponent makes a scale necessary:
 //                         s is the power of two that puts the tensor's largest magnitude in [2^14, 2^15) -- the largest value is
 //                         below fp16's 65504, an element 2^-17 of the maximum or larger keeps a normal hi (11 bits), and lo reaches
-//                         down to fp16's subnormal quantum 2^-24, i.e. 2^-38 of the maximum.  The dropped lo*lo is ~2^-22; measured
-//                         (tools/probe/split_precision_error.hip, profiles/r04_split_precision_error.log) the contraction's error
-//                         against fp64 is AT OR BELOW the exact-f32 MFMA's (2.7e-7 vs 3.2e-7 at K = 576, 5.4e-7 vs 6.5e-7 at
-//                         K = 2304): the f32 chain rounds its accumulator K times, this one K/16 x 3 times.
-// The largest magnitude travels as its fp32 BIT PATTERN in a device word ("absmax slot", faoctasr_absmax_bits): non-negative floats
-// order like unsigned integers, so the reduction is an atomicMax and nobody divides.
+//                         down to fp16's subnormal quantum 2^-24, i.e. 2^-38 of the maximum.  The dropped lo*lo is ~2^-22.
+//                         Measured against fp64 the contraction is in the exact-f32 MFMA's error class: in a bare 32 x 32 tile
+//                         (tools/probe/split_precision_error.hip, profiles/r04_split_precision_error.log) 2.7e-7 vs the f32 chain's
+//                         3.2e-7 at K = 576, 5.4e-7 vs 6.5e-7 at K = 2304 -- the f32 chain rounds its accumulator K times, this one
+//                         3 K / 16 times; against the shipped f32 KERNELS, which split their reduction over chunks and blocks,
+//                         0.65x .. 1.7x of their error per layer and operand, mean 0.97x over 94 measurements
+//                         (tests/test_gpu_ops.py::test_conv2d_f16x2, profiles/r04_f16x2_layer_errors.txt); bf16x3 is ~15x above both.
+// The largest magnitude travels as its fp32 BIT PATTERN ("absmax slot", faoctasr_absmax_bits): non-negative floats order like unsigned
+// integers, so the reduction is an atomicMax and nobody divides.  A slot is FAOCTASR_ABSMAX_SLOT_WORDS = 128 words (512 B) of which
+// 8 are used, one per 64-byte line: float atomics execute at the memory side, one address at a time (~8 ns each) -- the 2048 blocks
+// of a producer all finishing together cost 65 us on ONE word (measured: BatchNorm kernels 34 -> 100 us) and ~1 us spread over 8
+// lines after a block-level reduction.  Readers take the maximum of the 8 words (absmax_read).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,6 +24,32 @@ namespace faoctasr {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
+
+constexpr int ABSMAX_PARTS = 8, ABSMAX_STRIDE = 16;               // include/faoctasr.h: FAOCTASR_ABSMAX_SLOT_WORDS = PARTS * STRIDE
+__device__ __forceinline__ unsigned absmax_read(const unsigned* __restrict__ slot) {
+    unsigned m = slot[0];
+#pragma unroll
+    for (int i = 1; i < ABSMAX_PARTS; ++i) {
+        const unsigned v = slot[i * ABSMAX_STRIDE];
+        m = v > m ? v : m;
+    }
+    return m;
+}
+// a block's maximum (fp32 bits, all 256 threads call; red: 4 words of LDS) into the part chosen by its block id
+__device__ __forceinline__ void absmax_publish_block(unsigned mx, unsigned* __restrict__ slot, unsigned* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = red[0];
+        for (unsigned i = 1; i < (blockDim.x >> 6); ++i) m = red[i] > m ? red[i] : m;
+        if (m) atomicMax(slot + ((blockIdx.x + blockIdx.y) & (ABSMAX_PARTS - 1)) * ABSMAX_STRIDE, m);
+    }
+}
 
 // s = 2^(141 - e) for a maximum 1.m x 2^(e - 127): max * s = 1.m x 2^14.  Tensors whose maximum is zero, subnormal-small (< 2^-111),
 // infinite or NaN are left unscaled.

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
     if (producer) {
         // ================================================ PRODUCER ================================================
         float sx = 1.f, sd = 1.f;
-        if constexpr (F16) { sx = f16x2_scale(*x_slot); sd = f16x2_scale(*dy_slot); }
+        if constexpr (F16) { sx = f16x2_scale(absmax_read(x_slot)); sd = f16x2_scale(absmax_read(dy_slot)); }
         // ---- staging maps (tile-invariant; addresses of LDS buffer 0) ----
         // dY item i (2 per thread): row m = it >> 3, chunk = it & 7 -> tile row chunk >> 2, pixels 8 (chunk & 3) .. +7
         unsigned dg_off[2], dl_off[2];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
     float* stage = reinterpret_cast<float*>(smem) + wave * 2304;
     const long col_base = (long)(c0 + cb * 32) * g.wsc;
     float inv = 1.f;
-    if constexpr (F16) inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*dy_slot);
+    if constexpr (F16) inv = f16x2_inv_scale(absmax_read(x_slot)) * f16x2_inv_scale(absmax_read(dy_slot));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                                        // rows 8 j .. 8 j + 7 of the wave's 32 = registers 4 j .. 4 j + 3 of both lane halves
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 
     if (producer) {
         float sx = 1.f, sd = 1.f;
-        if constexpr (F16) { sx = f16x2_scale(*x_slot); sd = f16x2_scale(*dy_slot); }
+        if constexpr (F16) { sx = f16x2_scale(absmax_read(x_slot)); sd = f16x2_scale(absmax_read(dy_slot)); }
         unsigned dg_off[2], dl_off[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
     float* stage = reinterpret_cast<float*>(smem) + wave * (8 * 32 * KW);
     const long col_base = (long)(c0 + cb * 32) * g.wsc + (long)kh * KW;
     float inv = 1.f;
-    if constexpr (F16) inv = f16x2_inv_scale(*x_slot) * f16x2_inv_scale(*dy_slot);
+    if constexpr (F16) inv = f16x2_inv_scale(absmax_read(x_slot)) * f16x2_inv_scale(absmax_read(dy_slot));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll

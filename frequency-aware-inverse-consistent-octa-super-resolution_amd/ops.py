@@ -63,11 +63,12 @@ def invalidate_weight_cache():
 # ----------------------------------------------------------------------------------------
 # absmax slots of the f16x2 contraction (include/faoctasr.h: faoctasr_absmax_bits, faoctasr_conv_set_scales)
 # ----------------------------------------------------------------------------------------
-#: per HIP stream: (zeroed fp32 arena, cursor).  A slot is one word holding max|x| of an activation tensor (its fp32 bit pattern IS
-#: the float).  One arena per stream, because a slot is zeroed, filled and first read in stream order -- handing slots of one
+#: per HIP stream: (zeroed fp32 arena, cursor).  A slot is SLOT_WORDS words whose maximum is max|x| of an activation tensor (the fp32
+#: bit pattern IS the float).  One arena per stream, because a slot is zeroed, filled and first read in stream order -- handing slots of one
 #: arena to several streams would let a reader overtake the fill.
 _scale_arenas = {}
-SCALE_ARENA_SLOTS = 2048
+SCALE_ARENA_SLOTS = 1024
+SLOT_WORDS = 128                                # include/faoctasr.h FAOCTASR_ABSMAX_SLOT_WORDS: 8 used words, one per 64-byte line
 
 
 def reset_scale_arenas():
@@ -80,10 +81,10 @@ def _new_slot(device):
     sid = stream_ptr()
     ent = _scale_arenas.get(sid)
     if ent is None or ent[1] >= SCALE_ARENA_SLOTS or ent[0].device != device:
-        ent = _scale_arenas[sid] = [torch.zeros(SCALE_ARENA_SLOTS, dtype=torch.float32, device=device), 0]
+        ent = _scale_arenas[sid] = [torch.zeros(SCALE_ARENA_SLOTS * SLOT_WORDS, dtype=torch.float32, device=device), 0]
     i = ent[1]
     ent[1] = i + 1
-    return ent[0][i:i + 1]
+    return ent[0][i * SLOT_WORDS:(i + 1) * SLOT_WORDS]
 
 
 def absmax_slot(t):
@@ -98,6 +99,22 @@ def absmax_slot(t):
     call("absmax_bits", ptr(t), t.numel(), ptr(slot), sid)
     t._fa_absmax = (slot, t._version, sid)
     return slot
+
+
+def _producer_slot(x, C, H, W):
+    """A fresh absmax slot handed to the NEXT BatchNorm call (``faoctasr_out_absmax``) when its output can feed a split-precision
+    convolution (>= 16 channels, a map >= 24 wide, H*W a multiple of 4); None otherwise."""
+    if conv_precision != 3 or C < 16 or W < 24 or (H * W) & 3:
+        return None
+    slot = _new_slot(x.device)
+    call("out_absmax", ptr(slot))
+    return slot
+
+
+def _tag_absmax(t, slot):
+    """``t``'s producer has folded max|t| into ``slot`` on the current stream: ``absmax_slot(t)`` will find it."""
+    if slot is not None:
+        t._fa_absmax = (slot, t._version, stream_ptr())
 
 
 def _wants_scale(C, IW, OW):
@@ -447,6 +464,7 @@ class _BatchNormTrain(Function):
         stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
         ws = _lib.workspace(x.device, C * 128)
         sp = stats.data_ptr()                   # (row views cost ~3 us each on the host: 243 calls per step)
+        slot = _producer_slot(x, C, H, W)       # f16x2: the output's largest magnitude comes out of this kernel's store loop
         call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), sp, sp + 4 * C,
              ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr())
         # the backward takes the ReLU / LeakyReLU mask from x when there was no residual (faoctasr.h): y is then not kept by this node
@@ -456,6 +474,7 @@ class _BatchNormTrain(Function):
         ctx.cfg = (act, slope, residual is not None)
         ctx.mark_non_differentiable(stats)
         ctx.set_materialize_grads(False)          # no zero-filled gradient tensor for `stats` on every backward
+        _tag_absmax(y, slot)
         return y, stats
 
     @staticmethod
@@ -481,9 +500,11 @@ class _BatchNormTrain(Function):
             dres = torch.empty_like(x) if act else dy
         ws = _lib.workspace(x.device, C * 128)
         sp = stats.data_ptr()
+        slot = _producer_slot(x, C, H, W)       # f16x2: dx is the dY of the convolution in front of this layer
         call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), sp, sp + 4 * C, ptr(dx),
              ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
              N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
+        _tag_absmax(dx, slot)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None
 
 

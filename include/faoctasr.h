@@ -70,22 +70,29 @@ long faoctasr_conv_pack_job(void* job_host, long block_base, int kind, const flo
                             int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                             int reflect, int out_pad, int precision);
 int faoctasr_conv_pack_run(const void* jobs_dev, int njobs, long nblocks, faoctasr_stream_t stream);
-/* precision 3 ("f16x2") tables only, BEFORE faoctasr_conv_pack_run on the same stream: the absmax slot of every job's weight
- * tensor (one block per job; the slot is the last word of the job's image).                                              */
+/* precision 3 ("f16x2") tables only, BEFORE faoctasr_conv_pack_run on the same stream: the absmax slots of every job's weight
+ * tensor (8 blocks per job, one partial maximum each, in the last 8 words of the job's image).                          */
 int faoctasr_conv_pack_scales(const void* jobs_dev, int njobs, faoctasr_stream_t stream);
 /* ---- precision 3, "f16x2": fp32-exact-class contraction at the 16-bit matrix-core rate ------------------------------
  * Every fp32 operand is split into hi = f16(x s), lo = f16(x s - hi) (22 significant bits) and a product is accumulated in
  * fp32 as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16; s is the power of two that puts the operand tensor's largest
  * magnitude in [2^14, 2^15) and is divided out of the accumulators.  Measured against fp64 the result is at or below the
  * error of the exact-f32 MFMA kernels (csrc/split16.h, profiles/r04_split_precision_error.log), at ~5x their rate.
- * The largest magnitude of an ACTIVATION operand travels as its fp32 bit pattern in a caller-owned device word, the
- * "absmax slot": zero the word, then faoctasr_absmax_bits(x, n, slot) (an atomicMax: several calls may fold several
- * tensors into one slot).  The slots of the next convolution-type call of the calling thread are handed over with
+ * The largest magnitude of an ACTIVATION operand travels as its fp32 bit pattern in a caller-owned "absmax slot" of
+ * FAOCTASR_ABSMAX_SLOT_WORDS device words (512 bytes; 8 of them are used, one per 64-byte line, so that the producers' atomics
+ * do not queue on one address; a reader takes their maximum): zero the slot, then faoctasr_absmax_bits(x, n, slot) (atomicMax:
+ * several calls may fold several tensors into one slot).  The slots of the next convolution-type call of the calling thread are handed over with
  * faoctasr_conv_set_scales(a, b): gather calls (conv2d_fwd / dgrad, conv_transpose2d_fwd / dgrad) read `a` = the slot of their
  * gathered tensor (x, resp. dy); weight-gradient calls read `a` = slot of x and `b` = slot of dy.  The call consumes them
  * (a precision-3 call without slots fails with FAOCTASR_EINVAL); the weights' own slot lives in the packed image.  Shapes
  * the split kernels do not take (maps narrower than 24, fewer than 16 channels) silently run on the exact-f32 kernels. */
+#define FAOCTASR_ABSMAX_SLOT_WORDS 128
 int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream);
+/* The producer's side of the same slot: the NEXT faoctasr_batchnorm_train_fwd (its y) / faoctasr_batchnorm_train_bwd (its dx) call
+ * of the calling thread folds the largest magnitude of its output into `slot` (zeroed by the caller) in its own store loop, so
+ * the convolution that reads that tensor needs no separate faoctasr_absmax_bits pass over it.  Map sizes (H*W) that are not a
+ * multiple of 4 are refused (FAOCTASR_EUNSUPPORTED): use faoctasr_absmax_bits there.                                       */
+int faoctasr_out_absmax(unsigned* slot);
 int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b);
 /* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
  * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with

@@ -769,6 +769,47 @@ def test_conv_transpose2d_f16x2(fa, case):
         assert e16 <= 1.6 * e32 + 5e-8, (case, what, e32, e16)
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 64, 64), (2, 64, 24, 40), (8, 16, 128, 128)])
+def test_absmax_slots_standalone_and_fused(fa, shape):
+    """The f16x2 scales come from absmax slots (include/faoctasr.h): faoctasr_absmax_bits over a tensor, and the same maximum
+    folded into the slot by the BatchNorm forward / backward kernels' own store loops (faoctasr_out_absmax) -- small-row and
+    streaming forms.  Both must give exactly max|t| (as its fp32 bit pattern), and the autograd ops must hand the fused slot to
+    the convolution that reads the tensor (no second pass: ``absmax_slot`` returns the producer's slot)."""
+    from faoctasr._lib import call, ptr, stream_ptr
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = dev(torch.randn(N, C, H, W, generator=g) * 3 + 0.5)
+    slot = torch.zeros(fa.ops.SLOT_WORDS, device="cuda")
+    call("absmax_bits", ptr(x), x.numel(), ptr(slot), stream_ptr())
+    assert float(slot.max()) == float(x.abs().max()) and int((slot != 0).sum()) <= 8
+    odd = x.reshape(-1)[: x.numel() - 3]                        # a length that is not a multiple of 4 (scalar tail)
+    slot.zero_()
+    call("absmax_bits", ptr(odd), odd.numel(), ptr(slot), stream_ptr())
+    assert float(slot.max()) == float(odd.abs().max())
+    gamma, beta = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g))
+    fa.ops.conv_precision = 3
+    try:
+        xr = x.clone().requires_grad_(True)
+        y = fa.ops.batchnorm_train(xr, gamma, beta, None, None, 0.1, 1e-5, "relu", 0.2)
+        tag = getattr(y, "_fa_absmax", None)
+        assert tag is not None and float(tag[0].max()) == float(y.detach().abs().max())
+        assert fa.ops.absmax_slot(y) is tag[0]                  # the consumer takes the producer's slot
+        cot = dev(torch.randn(N, C, H, W, generator=g) * 1e-3)
+        seen = {}
+        def grab(gr):
+            seen["dx"] = (getattr(gr, "_fa_absmax", None), gr)
+        hook = xr.register_hook(grab)
+        y.backward(cot)
+        hook.remove()
+        tag_dx, gr = seen["dx"]
+        assert tag_dx is not None and float(tag_dx[0].max()) == float(gr.abs().max())
+    finally:
+        fa.ops.conv_precision = 0
+    y0 = fa.ops.batchnorm_train(x, gamma, beta, None, None, 0.1, 1e-5, "relu", 0.2)
+    assert getattr(y0, "_fa_absmax", None) is None             # other precisions: no slot, nothing extra launched
+    assert torch.equal(y0, y)
+
+
 def test_input_pipeline_vs_oracle(fa, O):
     """fused crop + bicubic x2 + normalise (transforms_A) and crop + normalise (transforms_B) against the oracle's
     ATen restatement of train.py:129-140, including border crops (clamped bicubic taps) and a non-square source."""
