@@ -313,10 +313,6 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                     if (NT * i < nqi) {                                  // block-uniform (hook() issues a DMA: every lane must be there);
                         const bool qok = q_pos[i] >= 0;                  // lanes without an item compute on zeros and store nothing
                         const int px0 = ((q_pos[i] >> 8) & 0xff) - 4;
-                        if constexpr (F16) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) qv[i][j] *= sx;
-                        }
                         // hi = bf16(x) of two CHANNELS of a pixel is one v_cvt_pk_bf16_f32 (the LDS order); x - float(hi) of two PIXELS
                         // of a channel is one v_pk_add_f32 on the register pair the dwordx4 load left them in: 2.5 instructions per
                         // element and no moves (pairing channels for the subtraction cost two v_mov per pair)
@@ -324,6 +320,17 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
 #pragma unroll
                         for (int kp = 0; kp < 2; ++kp) {
                             unsigned hd[2][4], ld[2][4];                 // [pixel of the pair][channel pair]
+                            if constexpr (F16) {
+                                // f16x2: a channel pair of a pixel is four v_fma_mix*_f16 (scale, convert, widen, subtract, convert: split16.h)
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                                    for (int c2 = 0; c2 < 4; ++c2) {
+                                        split_pair_scaled<true>(qv[i][2 * c2][2 * kp + k], qv[i][2 * c2 + 1][2 * kp + k], sx, hd[k][c2], ld[k][c2]);
+                                        if (c2 & 1) hook();
+                                    }
+                                }
+                            } else {
                             f32x2s lo[8];                                // [channel]
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
 #pragma unroll
                                 for (int c2 = 0; c2 < 4; ++c2)
                                     ld[k][c2] = cvt_pair<F16>(lo[2 * c2][k], lo[2 * c2 + 1][k]);
+                            }
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
                                 if (qok && (unsigned)(px0 + 2 * kp + k) < (unsigned)PW) {       // not: a covering piece's columns beyond the patch row
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         unsigned h, l;
-                        split_pair<F16>(pv[i][2 * j] * sx, pv[i][2 * j + 1] * sx, h, l);
+                        split_pair_scaled<F16>(pv[i][2 * j], pv[i][2 * j + 1], sx, h, l);
                         hv[j] = h;
                         lv[j] = l;
                     }

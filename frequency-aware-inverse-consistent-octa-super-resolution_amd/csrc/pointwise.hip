@@ -467,7 +467,7 @@ __global__ void prep_crop_resize_kernel(const unsigned char* __restrict__ img, c
 __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ slot) {
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
     unsigned mx = 0;
-    const long n4 = n >> 2;
+    const long n4 = (reinterpret_cast<unsigned long>(x) & 15) ? 0 : n >> 2;      // an operand that starts off a 16-byte boundary: scalar loads
     const u32x4v* x4 = reinterpret_cast<const u32x4v*>(x);
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -718,7 +718,6 @@ int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const i
 
 int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream) {
     if (!x || !slot) return fail(FAOCTASR_EINVAL, "absmax_bits: null pointer");
-    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(FAOCTASR_EINVAL, "absmax_bits: x must be 16-byte aligned");
     if (n <= 0) return FAOCTASR_OK;
     hipLaunchKernelGGL(absmax_bits_kernel, dim3(grid_for(n, 8192, 2048)), dim3(256), 0, (hipStream_t)stream, x, n, slot);
     return check_launch("absmax_bits");

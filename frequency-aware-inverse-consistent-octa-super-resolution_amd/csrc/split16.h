@@ -91,6 +91,25 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     }
 }
 
+// (a, b) and the tensor's scale -> hi = {f16(a s), f16(b s)}, lo = {f16(a s - hi.a), f16(b s - hi.b)}.  F16: four v_fma_mix*_f16 -- the
+// mixed-precision FMA multiplies by the scale, widens its f16 operand, subtracts and rounds to f16 in ONE instruction per value
+// (2 per element against 3 + register-pair moves for the convert / widen / subtract / convert sequence; bit-identical to it:
+// a s is exact, a s - hi is exact in fp32, and each result is rounded once).  bf16: no scale (s is ignored).
+template <bool F16>
+__device__ __forceinline__ void split_pair_scaled(float a, float b, float s, unsigned& hi, unsigned& lo) {
+    if constexpr (F16) {
+        unsigned h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(s), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(s), "v"(h));
+        hi = h;
+        lo = l;
+    } else {
+        split_pair<false>(a, b, hi, lo);
+    }
+}
+
 // the fp32 value of the low / high 16-bit half of a packed pair
 template <bool F16>
 __device__ __forceinline__ float half_lo_f32(unsigned d) {

@@ -173,11 +173,10 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                if constexpr (F16) { dv[i][0] *= sd; dv[i][1] *= sd; }
-                split_pair<F16>(dv[i][0][0], dv[i][0][1], h0, l0);
-                split_pair<F16>(dv[i][0][2], dv[i][0][3], h1, l1);
-                split_pair<F16>(dv[i][1][0], dv[i][1][1], h2, l2);
-                split_pair<F16>(dv[i][1][2], dv[i][1][3], h3, l3);
+                split_pair_scaled<F16>(dv[i][0][0], dv[i][0][1], sd, h0, l0);
+                split_pair_scaled<F16>(dv[i][0][2], dv[i][0][3], sd, h1, l1);
+                split_pair_scaled<F16>(dv[i][1][0], dv[i][1][1], sd, h2, l2);
+                split_pair_scaled<F16>(dv[i][1][2], dv[i][1][3], sd, h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 const unsigned da = dl_off[i] + bo;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
@@ -187,15 +186,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
             for (int i = 0; i < 3; ++i) {
                 if (x_row[i] < 0) continue;
                 const unsigned xa = xl_off[i] + bo;
-                if constexpr (F16) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) xv[i][c] *= sx;
-                }
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {                         // one pixel's four channels -> 8 bytes per plane
                     unsigned h0, h1, l0, l1;
-                    split_pair<F16>(xv[i][0][px], xv[i][1][px], h0, l0);
-                    split_pair<F16>(xv[i][2][px], xv[i][3][px], h1, l1);
+                    split_pair_scaled<F16>(xv[i][0][px], xv[i][1][px], sx, h0, l0);
+                    split_pair_scaled<F16>(xv[i][2][px], xv[i][3][px], sx, h1, l1);
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + X3_XPLANE) : "memory");
@@ -445,11 +440,10 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-                if constexpr (F16) { dv[i][0] *= sd; dv[i][1] *= sd; }
-                split_pair<F16>(dv[i][0][0], dv[i][0][1], h0, l0);
-                split_pair<F16>(dv[i][0][2], dv[i][0][3], h1, l1);
-                split_pair<F16>(dv[i][1][0], dv[i][1][1], h2, l2);
-                split_pair<F16>(dv[i][1][2], dv[i][1][3], h3, l3);
+                split_pair_scaled<F16>(dv[i][0][0], dv[i][0][1], sd, h0, l0);
+                split_pair_scaled<F16>(dv[i][0][2], dv[i][0][3], sd, h1, l1);
+                split_pair_scaled<F16>(dv[i][1][0], dv[i][1][1], sd, h2, l2);
+                split_pair_scaled<F16>(dv[i][1][2], dv[i][1][3], sd, h3, l3);
                 const u32x4 hi = {h0, h1, h2, h3}, lo = {l0, l1, l2, l3};
                 const unsigned da = dl_off[i] + bo;
                 asm volatile("ds_write_b128 %0, %1" ::"v"(da), "v"(hi) : "memory");
@@ -461,16 +455,15 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
                 const unsigned xa = xl_off[i] + bo;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                            // mirrored border chunks (reflection only)
-                    f32x4 v = xv[i][c];
-                    if constexpr (F16) v *= sx;
+                    const f32x4 v = xv[i][c];
                     const f32x4 l = {v[0], v[3], v[2], v[1]}, r = {v[2], v[1], v[0], v[3]};
                     xv[i][c] = flip[i] == 1 ? l : (flip[i] == 2 ? r : v);
                 }
 #pragma unroll
                 for (int px = 0; px < 4; ++px) {
                     unsigned h0, h1, l0, l1;
-                    split_pair<F16>(xv[i][0][px], xv[i][1][px], h0, l0);
-                    split_pair<F16>(xv[i][2][px], xv[i][3][px], h1, l1);
+                    split_pair_scaled<F16>(xv[i][0][px], xv[i][1][px], sx, h0, l0);
+                    split_pair_scaled<F16>(xv[i][2][px], xv[i][3][px], sx, h1, l1);
                     const u32x2 hi = {h0, h1}, lo = {l0, l1};
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(hi), "n"(64 * px) : "memory");
                     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(xa), "v"(lo), "n"(64 * px + R::XPLANE) : "memory");
