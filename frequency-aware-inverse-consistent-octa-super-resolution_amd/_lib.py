@@ -23,6 +23,9 @@ _SIG = {
     "absmax_bits": (_I, "p l p p"),
     "conv_set_scales": (_I, "pp"),
     "out_absmax": (_I, "p"),
+    "conv_set_workspace": (_I, "p l"),
+    "conv_set_residual": (_I, "p"),
+    "conv_wgrad_workspace_floats": (_L, "iiiii"),
     "conv2d_fwd": (_I, "pppp iiiiiiiii i i f p i i p"),
     "conv2d_dgrad": (_I, "ppp iiiiiiiii p i i p"),
     "conv2d_wgrad": (_I, "ppp iiiiiiiii i i i p"),
@@ -154,10 +157,10 @@ def call(name, *args):
 _ws = {}
 
 
-def workspace(device, nfloats):
-    """Per-(device, stream) scratch reused by the stream-ordered reduction kernels."""
+def workspace(device, nfloats, tag=None):
+    """Per-(device, stream[, tag]) scratch reused by the stream-ordered reduction kernels."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
+    key = (idx, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream, tag)
     t = _ws.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)

@@ -452,10 +452,23 @@ static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || 
 // the absmax slots faoctasr_conv_set_scales left for this thread's next convolution-type call: taken (and cleared) by that call
 thread_local const unsigned* g_scale_a = nullptr;
 thread_local const unsigned* g_scale_b = nullptr;
+thread_local float* g_wgrad_ws = nullptr;
+thread_local long g_wgrad_ws_floats = 0;
+// a weight-gradient entry takes the workspace for the duration of the call and clears it on every way out
+struct WgradWsScope {
+    ~WgradWsScope() { g_wgrad_ws = nullptr; g_wgrad_ws_floats = 0; }
+};
 static const unsigned* take_scale_a() {
     const unsigned* a = g_scale_a;
     g_scale_a = g_scale_b = nullptr;
     return a;
+}
+// the tensor faoctasr_conv_set_residual left for this thread's next gather call
+thread_local const float* g_conv_residual = nullptr;
+static const float* take_residual() {
+    const float* r = g_conv_residual;
+    g_conv_residual = nullptr;
+    return r;
 }
 
 // wpack_state: 0 = no pack buffer (flat kernel), 1 = pack the weights into wpack now, 2 = wpack already holds them
@@ -464,7 +477,19 @@ static const unsigned* take_scale_a() {
 // sink: record the weight-packing job this call would launch (wpack_state 1) and launch nothing (faoctasr_conv_pack_job);
 // sink->blocks stays 0 when the call's route uses no packed image.
 static int run_gather(const float* x, const float* w, const float* bias, float* y, IgemmGeom& g, int act, float slope, float* wpack,
-                      int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr, const unsigned* slot_a = nullptr) {
+                      int wpack_state, int precision, hipStream_t s, PackJob* sink = nullptr, const unsigned* slot_a = nullptr,
+                      const float* res = nullptr) {
+    // res (faoctasr_conv_set_residual): y = gather(...) + res.  The split kernels add it in their epilogue; every other route runs
+    // as usual and is followed by one in-place y += res pass.
+    if (res && !sink) {
+        if (wpack && wpack_state && (precision & 0xff) >= 2) {
+            const int rc = split_try(g, x, w, bias, y, act, slope, wpack, wpack_state, s, nullptr, (precision & 0xff) == 3, slot_a, res);
+            if (rc != 0) { set_route(ROUTE_BF16X3); return rc < 0 ? rc : FAOCTASR_OK; }
+        }
+        const int rc = run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, s, nullptr, slot_a, nullptr);
+        if (rc) return rc;
+        return faoctasr_axpby(y, res, y, (long)g.N * g.M * g.OH * g.OW, 1.f, 1.f, (faoctasr_stream_t)s);
+    }
     // FAOCTASR_CONV_NO_SPLIT_K: a reproducible result (one block owns the whole reduction of an output element) for this call
     struct Scope { int prev; Scope(int v) : prev(g_no_split_k) { g_no_split_k = v; } ~Scope() { g_no_split_k = prev; } } scope((precision & FAOCTASR_CONV_NO_SPLIT_K) ? 1 : 0);
     precision &= 0xff;
@@ -588,10 +613,34 @@ int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b) {
     return FAOCTASR_OK;
 }
 
+int faoctasr_conv_set_residual(const float* residual) {
+    g_conv_residual = residual;
+    return FAOCTASR_OK;
+}
+
+int faoctasr_conv_set_workspace(float* ws, long nfloats) {
+    g_wgrad_ws = ws;
+    g_wgrad_ws_floats = ws ? nfloats : 0;
+    return FAOCTASR_OK;
+}
+
+long faoctasr_conv_wgrad_workspace_floats(int C, int M, int KH, int KW, int stride) {
+    // slices x the extent of dW; slices = the pixel ranges of a one-block-per-CU grid: 256 / ((C / 64) (M / 64)) for the stride-1 3x3
+    // kernel, a further / KH for the kernels that give every kernel row its own block (wgrad_x3.hip)
+    if (C <= 0 || M <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return fail(FAOCTASR_EINVAL, "conv_wgrad_workspace_floats: bad shape");
+    if ((C & 63) || (M & 63)) return 0;                   // not a shape the split weight-gradient kernels take
+    long blocks = (long)(C / 64) * (M / 64);
+    if (!(stride == 1 && KH == 3)) blocks *= KH;
+    long slices = 256 / blocks;
+    slices = slices < 1 ? 1 : slices;
+    return slices * (long)C * M * KH * KW;
+}
+
 int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int IH, int IW, int M,
                         int KH, int KW, int stride, int pad, int reflect, int act, float slope, float* wpack, int wpack_state,
                         int precision, faoctasr_stream_t stream) {
     const unsigned* const slot_a = take_scale_a();
+    const float* const res = take_residual();
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv2d_fwd: null pointer");
     if (N < 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0) return fail(FAOCTASR_EINVAL, "conv2d_fwd: bad shape");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
@@ -599,35 +648,43 @@ int faoctasr_conv2d_fwd(const float* x, const float* w, const float* bias, float
     if (M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32)
     {
         set_route(ROUTE_M1_FWD);
-        return launch_conv_m1_fwd(x, w, bias, y, N, C, IH, IW, KH, KW, pad, act, slope, (hipStream_t)stream);
+        const int rc1 = launch_conv_m1_fwd(x, w, bias, y, N, C, IH, IW, KH, KW, pad, act, slope, (hipStream_t)stream);
+        if (rc1 || !res) return rc1;
+        return faoctasr_axpby(y, res, y, (long)N * M * OH * OW, 1.f, 1.f, stream);
     }
     IgemmGeom g;
     int rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a, res);
 }
 
 int faoctasr_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW,
                           int stride, int pad, float* wpack, int wpack_state, int precision, faoctasr_stream_t stream) {
     const unsigned* const slot_a = take_scale_a();
+    const float* const res = take_residual();
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: null pointer");
     const int OH = (IH + 2 * pad - KH) / stride + 1, OW = (IW + 2 * pad - KW) / stride + 1;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv2d_dgrad: bad shape");
     {
         const int rc = launch_stem_dgrad(dy, w, dx, N, C, IH, IW, M, KH, KW, stride, pad, (hipStream_t)stream);
-        if (rc != 0) { set_route(ROUTE_STEM_DGRAD); return rc < 0 ? rc : FAOCTASR_OK; }
+        if (rc != 0) {
+            set_route(ROUTE_STEM_DGRAD);
+            if (rc < 0 || !res) return rc < 0 ? rc : FAOCTASR_OK;
+            return faoctasr_axpby(dx, res, dx, (long)N * C * IH * IW, 1.f, 1.f, stream);
+        }
     }
     IgemmGeom g;
     // source = dy [N,M,OH,OW] (gathered channels = M), output = dx [N,C,IH,IW]; w[m][c][t]
     int rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, (long)KH * KW, (long)C * KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a, res);
 }
 
 int faoctasr_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW,
                           int stride, int pad, int reflect, int accumulate, int precision, faoctasr_stream_t stream) {
     const unsigned *const slot_x = g_scale_a, *const slot_dy = g_scale_b;
     g_scale_a = g_scale_b = nullptr;
+    WgradWsScope ws_scope;
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv2d_wgrad: null pointer");
     precision &= 0xff;             // the weight gradients have no split-K policy to switch: they always accumulate with atomics
     if (precision < 0 || precision > 3) return fail(FAOCTASR_EINVAL, "unknown conv precision %d (0 = f32, 1 = f32 direct, 2 = bf16x3, 3 = f16x2)", precision);
@@ -671,6 +728,7 @@ int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* b
                                   int M, int KH, int KW, int stride, int pad, int out_pad, int act, float slope, float* wpack,
                                   int wpack_state, int precision, faoctasr_stream_t stream) {
     const unsigned* const slot_a = take_scale_a();
+    const float* const res = take_residual();
     if (bad_ptr(x, w, y)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_transpose2d_fwd: bad shape");
@@ -678,26 +736,28 @@ int faoctasr_conv_transpose2d_fwd(const float* x, const float* w, const float* b
     // w[c][m][t]: m stride = KK, c stride = M*KK
     int rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, (long)KH * KW, (long)M * KH * KW);
     if (rc) return rc;
-    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
+    return run_gather(x, w, bias, y, g, act, slope, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a, res);
 }
 
 int faoctasr_conv_transpose2d_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH,
                                     int KW, int stride, int pad, int out_pad, float* wpack, int wpack_state, int precision,
                                     faoctasr_stream_t stream) {
     const unsigned* const slot_a = take_scale_a();
+    const float* const res = take_residual();
     if (bad_ptr(dy, w, dx)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_dgrad: null pointer");
     const int OH = (IH - 1) * stride - 2 * pad + KH + out_pad, OW = (IW - 1) * stride - 2 * pad + KW + out_pad;
     IgemmGeom g;
     // dx[n][c][iy][ix] = sum_{m,t} dy[n][m][iy*s-p+kh][..] * w[c][m][t]: forward-mode gather over dy
     int rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * KH * KW, (long)KH * KW);
     if (rc) return rc;
-    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a);
+    return run_gather(dy, w, nullptr, dx, g, FAOCTASR_ACT_NONE, 0.f, wpack, wpack_state, precision, (hipStream_t)stream, nullptr, slot_a, res);
 }
 
 int faoctasr_conv_transpose2d_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH,
                                     int KW, int stride, int pad, int out_pad, int accumulate, int precision, faoctasr_stream_t stream) {
     const unsigned *const slot_x = g_scale_a, *const slot_dy = g_scale_b;
     g_scale_a = g_scale_b = nullptr;
+    WgradWsScope ws_scope;
     if (bad_ptr(x, dy, dw)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: null pointer");
     precision &= 0xff;
     if (precision == 3 && (!slot_x || !slot_dy)) return fail(FAOCTASR_EINVAL, "conv_transpose2d_wgrad: precision 3 (f16x2) needs both absmax slots: faoctasr_conv_set_scales");

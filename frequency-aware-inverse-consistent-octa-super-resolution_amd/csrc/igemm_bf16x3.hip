@@ -79,6 +79,7 @@ typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #endif
 
 constexpr int SP_MT = 64;         // output channels per block
+static thread_local bool g_conv_residual_live = false;               // (host) the call being dispatched carries a fused residual
 constexpr int SP_NPI = 6;         // (pixel, h) items staged per thread
 
 __device__ __forceinline__ int reflect_idx_s(int i, int n) {
@@ -154,7 +155,7 @@ template <int NI, int SI, bool QUAD, int NCW = 4, bool F16 = false>
 __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const float* __restrict__ x, const __bf16* __restrict__ wp,
                                                            const float* __restrict__ bias, float* __restrict__ y, const SplitGeom g,
                                                            const int ksplit, const int wide, const unsigned* __restrict__ x_slot,
-                                                           const unsigned* __restrict__ w_slot) {
+                                                           const unsigned* __restrict__ w_slot, const float* __restrict__ res) {
     constexpr int MI = 2, TH = NCW * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             const unsigned ohw = (unsigned)(g.OH * g.OW);
             const int bo = ctx * 32 + l31;
             float* const yimg = y + (long)cn * g.M * (long)ohw;
+            const float* const rimg = res ? res + (long)cn * g.M * (long)ohw : nullptr;
             const bool full_m = m0 + SP_MT <= g.M;
             if (wide) {
                 // 32 x 32 accumulator tile -> the wave's 4 KiB of staging (a lane holds ONE pixel of 16 rows) -> a lane reads 4
@@ -702,10 +704,12 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                         for (int rr = 0; rr < 16; ++rr) S[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * 32 + l31] = acc[mi][ni][rr];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const f32x4s v = *reinterpret_cast<const f32x4s*>(S + (prow + 8 * i) * 32 + 4 * pq);
+                            f32x4s v = *reinterpret_cast<const f32x4s*>(S + (prow + 8 * i) * 32 + 4 * pq);
                             const int dm = mi * 32 + 8 * i;
-                            if (ok && (full_m || m0 + prow + dm < g.M) && ((SP_ABLATE & 16) == 0 || v[0] == 123.456f))
+                            if (ok && (full_m || m0 + prow + dm < g.M) && ((SP_ABLATE & 16) == 0 || v[0] == 123.456f)) {
+                                if (res) v += *reinterpret_cast<const f32x4s*>(rimg + (o0 + (unsigned)dm * ohw));      // fused "+ residual" (faoctasr_conv_set_residual)
                                 *reinterpret_cast<f32x4s*>(yimg + (o0 + (unsigned)dm * ohw)) = v;
+                            }
                         }
                     }
                 }
@@ -722,8 +726,9 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                             const int dm = mi * 32 + (rr & 3) + 8 * (rr >> 2);
                             if ((full_m || mrow0 + dm < g.M) && ((SP_ABLATE & 16) == 0 || acc[mi][ni][rr] == 123.456f)) {
                                 float* const p = yimg + (o0 + (unsigned)dm * ohw);
-                                if (ksplit > 1) atomicAdd(p, acc[mi][ni][rr]);
-                                else *p = acc[mi][ni][rr];
+                                const float rv = (res && ks == 0) ? rimg[o0 + (unsigned)dm * ohw] : 0.f;
+                                if (ksplit > 1) atomicAdd(p, acc[mi][ni][rr] + rv);
+                                else *p = acc[mi][ni][rr] + rv;
                             }
                         }
                     }
@@ -852,7 +857,8 @@ int launch_split_pack(const float* w, float* wp, const SplitGeom& g, hipStream_t
 }
 
 template <int NI>
-static int sp_launch(const float* x, const float* wp, const float* bias, float* y, const SplitGeom& g, hipStream_t s, const unsigned* x_slot) {
+static int sp_launch(const float* x, const float* wp, const float* bias, float* y, const SplitGeom& g, hipStream_t s, const unsigned* x_slot,
+                     const float* res) {
     constexpr int TH = 4 * NI;
     long mx = 0;
     for (int p = 0; p < g.nphase; ++p) {
@@ -888,7 +894,7 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
     const unsigned* w_slot = reinterpret_cast<const unsigned*>(wp) + split_scale_slot(g);
     auto go = [&](auto k) {
         lds_optin((const void*)k, lds);
-        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit, wide, x_slot, w_slot);
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, ksplit, wide, x_slot, w_slot, res);
     };
     if (g.f16) {
         if (g.SI == 1) {
@@ -912,7 +918,7 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
 // for stride-1 single-phase layers whose 512-pixel tiles still give every CU at least two tiles, when the 4-pixel patch items and the
 // 16-byte epilogue apply; the tap group shrinks to <= 5 taps so that the two weight buffers leave room for the larger patch.
 static int sp_launch_wide_block(const float* x, const float* wp, const float* bias, float* y, SplitGeom g, hipStream_t s) {
-    if (!SP_NCW8 || g.f16 || g.SI != 1 || g.nphase != 1) return 0;
+    if (!SP_NCW8 || g.f16 || g_conv_residual_live || g.SI != 1 || g.nphase != 1) return 0;
     constexpr int TH = 16;
     const long tiles = (long)g.N * ((g.gw[0] + 31) / 32) * ((g.gh[0] + TH - 1) / TH);
     const int gy = (g.M + SP_MT - 1) / SP_MT;
@@ -931,24 +937,24 @@ static int sp_launch_wide_block(const float* x, const float* wp, const float* bi
     auto k = igemm_bf16x3_kernel<2, 1, true, 8>;
     lds_optin((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)nbx, gy, 1), dim3(768), lds, s, x, reinterpret_cast<const __bf16*>(wp), bias, y, g, 1, 1,
-                       (const unsigned*)nullptr, (const unsigned*)nullptr);
+                       (const unsigned*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
     const int rc = check_launch("igemm_bf16x3 (8 consumer waves)");
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 
 int launch_split(const float* x, const float* wp, const float* bias, float* y, SplitGeom& g, int act, float slope, hipStream_t s,
-                 const unsigned* x_slot) {
+                 const unsigned* x_slot, const float* res) {
     g.act = act; g.slope = slope;
     {
         const int rc = sp_launch_wide_block(x, wp, bias, y, g, s);
         if (rc != 0) return rc < 0 ? rc : FAOCTASR_OK;
     }
-    if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s, x_slot);
-    return sp_launch<1>(x, wp, bias, y, g, s, x_slot);
+    if (sp_fits(g, 2, g.SI)) return sp_launch<2>(x, wp, bias, y, g, s, x_slot, res);
+    return sp_launch<1>(x, wp, bias, y, g, s, x_slot, res);
 }
 
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s, PackJob* sink, int f16, const unsigned* x_slot) {
+              int wpack_state, hipStream_t s, PackJob* sink, int f16, const unsigned* x_slot, const float* res) {
     SplitGeom g;
     if (!split_geom_from(f, g, f16)) return 0;
     if (f16 && !sink && !x_slot) return fail(FAOCTASR_EINVAL, "precision 3 (f16x2) needs the gathered tensor's absmax slot: faoctasr_conv_set_scales");
@@ -960,7 +966,9 @@ int split_try(const IgemmGeom& f, const float* x, const float* w, const float* b
         const int rc = launch_split_pack(w, wpack, g, s);
         if (rc) return rc;
     }
-    const int rc = launch_split(x, wpack, bias, y, g, act, slope, s, x_slot);
+    g_conv_residual_live = res != nullptr;
+    const int rc = launch_split(x, wpack, bias, y, g, act, slope, s, x_slot, res);
+    g_conv_residual_live = false;
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 

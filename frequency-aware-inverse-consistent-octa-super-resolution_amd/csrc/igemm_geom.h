@@ -108,11 +108,15 @@ int launch_wgrad_s1(const float* x, const float* dy, float* dw, int N, int C, in
 // `sink` (wpack_state == 1 only): record the packing job there instead of launching anything -- 1 recorded, 0 not eligible
 // f16: 0 = bf16x3, 1 = f16x2 (x_slot: absmax slot of the gathered activation tensor, split16.h)
 int split_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
-              int wpack_state, hipStream_t s, PackJob* sink = nullptr, int f16 = 0, const unsigned* x_slot = nullptr);          // 1 launched, 0 not eligible, <0 error
+              int wpack_state, hipStream_t s, PackJob* sink = nullptr, int f16 = 0, const unsigned* x_slot = nullptr,
+              const float* res = nullptr);          // 1 launched, 0 not eligible, <0 error; res: y += res fused into the epilogue
 long split_pack_floats_for(const IgemmGeom& f);       // 0 when not eligible
 // the activation operands' absmax slots handed over by faoctasr_conv_set_scales for this thread's next convolution-type call
 extern thread_local const unsigned* g_scale_a;
 extern thread_local const unsigned* g_scale_b;
+// the workspace faoctasr_conv_set_workspace left for this thread's next weight-gradient call (two-pass reduction, wgrad_x3.hip)
+extern thread_local float* g_wgrad_ws;
+extern thread_local long g_wgrad_ws_floats;
 
 // Winograd F(2x2,3x3) fp32 kernel for dense stride-1 3x3 gathers (igemm_wino.hip)
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "split16.h"
+#include "igemm_geom.h"
 
 namespace faoctasr {
 
@@ -37,6 +38,7 @@ struct WgX3Geom {
     long wsm, wsc;           // dW element strides of row m / channel c (9 taps contiguous)
     int tiles_x, tiles_y, tiles_per_block;
     int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges
+    long dw_elems;           // extent of dW (two-pass reduction: a slice's partial dW is ws[slice * dw_elems ...])
 };
 
 constexpr int X3_DLD = 72;                         // dY row stride in LDS (bf16): 144 B rows, conflict-free ds_read_b128
@@ -73,7 +75,8 @@ __device__ __forceinline__ void x3_wait_set(bf16x8& ah, bf16x8& al, bf16x4 (&bh)
 // F16: f16x2 operands (split16.h): x and dY are staged as x * s(x_slot), dY * s(dy_slot); the scales are divided out before the atomics.
 template <bool F16>
 __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                       const WgX3Geom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot) {
+                                                       const WgX3Geom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot,
+                                                       float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -295,7 +298,9 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
         for (int i = 0; i < 36; ++i) {
             const int e = lane + 64 * i;                                 // element of [8 rows][288 = 32 channels x 9 taps]
             const int row = e / 288, col = e - row * 288;
-            atomicAdd(dw + (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + col, stage[e]);
+            const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + col;
+            if (ws) ws[(long)slice * g.dw_elems + o] = stage[e];         // two-pass: this slice's partial dW, plain stores (wgrad_reduce_kernel)
+            else atomicAdd(dw + o, stage[e]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -330,11 +335,13 @@ struct WgX3RowGeom {
     long wsm, wsc;           // dW element strides of row m / channel c (KH*KW taps contiguous)
     int tiles_x, tiles_y, tiles_per_block;
     int gx, gy, slices;      // 64-channel slabs, 64-row blocks, pixel ranges (x KH kernel rows)
+    long dw_elems;
 };
 
 template <int KW, int S, int PAD, bool F16>
 __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                                           const WgX3RowGeom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot) {
+                                                           const WgX3RowGeom g, const unsigned* __restrict__ x_slot, const unsigned* __restrict__ dy_slot,
+                                                           float* __restrict__ ws) {
     // wave-specialised like wgrad_x3_kernel (round 3): waves 0-3 contract, waves 4-7 stage into a double-buffered LDS image, a tile ahead
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -556,13 +563,62 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
             const int e = lane + 64 * i;                                 // element of [8 rows][32 channels][KW taps]
             if (e < 8 * 32 * KW) {
                 const int row = e / (32 * KW), rem = e - row * (32 * KW), ch = rem / KW, t = rem - ch * KW;
-                atomicAdd(dw + (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + (long)ch * g.wsc + t, stage[e]);
+                const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + (long)ch * g.wsc + t;
+                if (ws) ws[(long)slice * g.dw_elems + o] = stage[e];
+                else atomicAdd(dw + o, stage[e]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+}
+
+// Second pass of the two-pass weight-gradient reduction: dW[i] += sum over slices of ws[slice][i], slices in a FIXED order, one add
+// into dW per element.  The slices' partials were written with plain 6 TB/s stores instead of `slices` fp32 atomics per element
+// (1.3 TB/s chip-wide: 38 MB per launch on the 256 -> 256 and 64 -> 64 3x3 layers, 29 us of a 67 / 136 us kernel), and the sum no
+// longer depends on the order in which blocks finish: with every weight gradient of a step on ONE stream (TrainStep's side stream)
+// dW is bit-reproducible.  The final add stays an atomic because a captured step issues weight gradients of one layer from
+// several streams at once (train.TrainStep.capture_side_wgrad).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long elems, int slices) {
+    // block = 16 float4 elements x 16 slice groups: thread (e, grp) sums the slices grp, grp + 16, ... of its element (four loads in
+    // flight), the 16 group sums meet in LDS and are added in group order.  (One thread per element walking all slices was
+    // latency-bound: 23 us per launch for 38 MB, and 36 blocks on the 64 -> 64 layers.)
+    __shared__ f32x4 part[16][16];
+    const int e = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long i = ((long)blockIdx.x * 16 + e) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < elems) {
+        const float* p = ws + i;
+        int k = grp;
+        for (; k + 48 < slices; k += 64) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + (long)k * elems), b = *reinterpret_cast<const f32x4*>(p + (long)(k + 16) * elems);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p + (long)(k + 32) * elems), d = *reinterpret_cast<const f32x4*>(p + (long)(k + 48) * elems);
+            s += (a + b) + (c + d);
+        }
+        for (; k < slices; k += 16) s += *reinterpret_cast<const f32x4*>(p + (long)k * elems);
+    }
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && i < elems) {
+        f32x4 t = part[0][e];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += part[g][e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dw + i + j, t[j]);
+    }
+}
+
+static int launch_wgrad_reduce(const float* ws, float* dw, long elems, int slices, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems / 4 + 15) / 16)), dim3(256), 0, s, ws, dw, elems, slices);
+    return check_launch("wgrad_reduce");
+}
+
+// workspace of the two-pass reduction, or nullptr (atomics straight into dW) when the caller's is missing / too small / unaligned
+static float* x3_ws(long elems, int slices) {
+    float* ws = g_wgrad_ws;
+    if (!ws || (elems & 3) || (reinterpret_cast<uintptr_t>(ws) & 15) || g_wgrad_ws_floats < elems * slices) return nullptr;
+    return ws;
 }
 
 template <int KW, int S, int PAD, bool F16>
@@ -573,11 +629,14 @@ static int x3_row_go2(const float* x, const float* dy, float* dw, WgX3RowGeom& g
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    g.dw_elems = (long)g.M * g.wsm;
+    float* const ws = x3_ws(g.dw_elems, g.slices);
     auto k = wgrad_x3_row_kernel<KW, S, PAD, F16>;
     const size_t lds = 2 * (size_t)X3R<S>::LDS > (size_t)4 * 8 * 32 * KW * 4 ? 2 * (size_t)X3R<S>::LDS : (size_t)4 * 8 * 32 * KW * 4;
     lds_optin((const void*)k, lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.KH * g.slices)), dim3(512), lds, s, x, dy, dw, g, x_slot, dy_slot);
-    const int rc = check_launch("wgrad_x3_row");
+    hipLaunchKernelGGL(k, dim3((unsigned)(g.gx * g.gy * g.KH * g.slices)), dim3(512), lds, s, x, dy, dw, g, x_slot, dy_slot, ws);
+    int rc = check_launch("wgrad_x3_row");
+    if (rc == FAOCTASR_OK && ws) rc = launch_wgrad_reduce(ws, dw, g.dw_elems, g.slices, s);
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 template <int KW, int S, int PAD>
@@ -625,14 +684,17 @@ int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, in
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    g.dw_elems = (long)M * wsm;
+    float* const ws = x3_ws(g.dw_elems, g.slices);
     if (f16) {
         lds_optin((const void*)wgrad_x3_kernel<true>, 2 * X3_LDS);
-        hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot);
+        hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot, ws);
     } else {
         lds_optin((const void*)wgrad_x3_kernel<false>, 2 * X3_LDS);
-        hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot);
+        hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)(g.gx * g.gy * g.slices)), dim3(512), 2 * X3_LDS, s, x, dy, dw, g, x_slot, dy_slot, ws);
     }
-    const int rc = check_launch("wgrad_x3");
+    int rc = check_launch("wgrad_x3");
+    if (rc == FAOCTASR_OK && ws) rc = launch_wgrad_reduce(ws, dw, g.dw_elems, g.slices, s);
     return rc == FAOCTASR_OK ? 1 : rc;
 }
 

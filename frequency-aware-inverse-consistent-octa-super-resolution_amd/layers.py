@@ -51,11 +51,11 @@ class Conv2d(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
-    def forward(self, x, act=None, slope=0.2, reflect_pad=0, params=None):
+    def forward(self, x, act=None, slope=0.2, reflect_pad=0, params=None, link=None):
         w, b = params if params is not None else (self.weight, self.bias)
         if reflect_pad:
-            return ops.conv2d(x, w, b, self.stride, reflect_pad, True, act, slope)
-        return ops.conv2d(x, w, b, self.stride, self.padding, False, act, slope)
+            return ops.conv2d(x, w, b, self.stride, reflect_pad, True, act, slope, link)
+        return ops.conv2d(x, w, b, self.stride, self.padding, False, act, slope, link)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%d, stride=%d, padding=%d, bias=%s" % (
@@ -110,7 +110,7 @@ class BatchNorm2d(nn.Module):
         self._stat_epoch += 1
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, x, act=None, slope=0.2, residual=None):
+    def forward(self, x, act=None, slope=0.2, residual=None, link=None):
         if not self.training:
             y = ops.batchnorm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, None if residual is not None else act,
                                    slope)
@@ -123,7 +123,7 @@ class BatchNorm2d(nn.Module):
         d["_pending_batches"] += 1
         d["_stat_epoch"] += 1
         return ops.batchnorm_train(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps, act, slope,
-                                   residual)
+                                   residual, link)
 
 
 class InstanceNorm2d(nn.Module):

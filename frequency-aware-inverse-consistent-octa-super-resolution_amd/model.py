@@ -236,8 +236,11 @@ class _ResBlock(nn.Module):
             y = cb[0](x, act="relu", params=folded_conv_params(cb[0], cb[1]))
             y = ops.add(cb[3](y, params=folded_conv_params(cb[3], cb[4])), x)
             return ops.activation(y, post_act) if post_act else y
-        y = cb[1](cb[0](x), act="relu")
-        return cb[4](cb[3](y), act=post_act, residual=x)
+        # x receives two gradients: the skip's (from the last BatchNorm's backward) and the first convolution's input gradient.  The
+        # shared dict lets that convolution add the former in its own epilogue instead of autograd launching an elementwise add.
+        link = {} if (ops.fuse_residual_grad and x.requires_grad and torch.is_grad_enabled() and cb[4].training) else None
+        y = cb[1](cb[0](x, link=link), act="relu")
+        return cb[4](cb[3](y), act=post_act, residual=x, link=link)
 
 
 class ResnetBlock(_ResBlock):

@@ -20,6 +20,9 @@ _ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
 
 #: accumulate weight gradients in place into existing ``param.grad`` buffers
 direct_grad = True
+#: residual blocks hand the skip connection's gradient to their first convolution's input-gradient call (model._ResBlock,
+#: faoctasr_conv_set_residual) instead of leaving the add to autograd; False: plain autograd (tests compare the two)
+fuse_residual_grad = True
 
 
 def act_code(a):
@@ -115,6 +118,23 @@ def _tag_absmax(t, slot):
     """``t``'s producer has folded max|t| into ``slot`` on the current stream: ``absmax_slot(t)`` will find it."""
     if slot is not None:
         t._fa_absmax = (slot, t._version, stream_ptr())
+
+
+_wgrad_ws_need = {}
+
+
+def _wgrad_workspace(device, C, M, KH, KW, stride, prec):
+    """Hand the CURRENT stream's scratch buffer to the next weight-gradient call (two-pass reduction of the split kernels:
+    ``faoctasr_conv_set_workspace``).  Calls on one stream share the buffer; it is only live between the call's two launches."""
+    if prec < 2:
+        return
+    key = (C, M, KH, KW, stride)
+    n = _wgrad_ws_need.get(key)
+    if n is None:
+        n = _wgrad_ws_need[key] = _lib.load().faoctasr_conv_wgrad_workspace_floats(C, M, KH, KW, stride)
+    if n > 0:
+        ws = _lib.workspace(device, n + (1 << 16), tag="wgrad")
+        call("conv_set_workspace", ptr(ws), ws.numel())
 
 
 def _wants_scale(C, IW, OW):
@@ -281,7 +301,11 @@ def _grad_target(p):
 # ----------------------------------------------------------------------------------------
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act, slope):
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, slope, link=None):
+        """``link``: the dict a residual block shares between its first convolution and its last BatchNorm (``model._ResBlock``): the
+        BatchNorm's backward leaves the skip connection's gradient there (``link["dres"]``) instead of returning it to autograd, and
+        this convolution's input gradient is computed as dgrad(dy) + dres in one kernel (``faoctasr_conv_set_residual``)."""
+        ctx.link = link
         x, w = _c(x), _c(w)
         N, C, IH, IW = x.shape
         M, Cw, KH, KW = w.shape
@@ -319,9 +343,14 @@ class _Conv2d(Function):
             dy = g
         dx = dw = db = None
         sdy = absmax_slot(dy) if _wants_scale(M, IW, dy.shape[3]) else None
+        res = ctx.link.pop("dres", None) if ctx.link is not None else None
+        if res is not None and not ctx.needs_input_grad[0]:
+            raise _lib.KernelError("a residual link left a skip gradient for a convolution whose input needs no gradient")
         if ctx.needs_input_grad[0]:
             if sdy is not None:
                 call("conv_set_scales", ptr(sdy), None)
+            if res is not None and not reflect:
+                call("conv_set_residual", ptr(_c(res)))
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
                 wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
@@ -330,6 +359,8 @@ class _Conv2d(Function):
                 _packed(ent, wst)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
+                if res is not None:
+                    call("axpby", ptr(dx), ptr(_c(res)), ptr(dx), dx.numel(), 1.0, 1.0, st)
             else:
                 dx = torch.empty_like(x)
                 wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH, IW, M, KH, KW, stride, pad))
@@ -350,6 +381,7 @@ class _Conv2d(Function):
             def wgrad(s, out, accumulate):
                 if sx is not None:
                     call("conv_set_scales", ptr(sx), ptr(sdy))
+                _wgrad_workspace(x.device, C, M, KH, KW, stride, prec)
                 call("conv2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, prec, s)
             if tgt is not None:
                 _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
@@ -362,11 +394,11 @@ class _Conv2d(Function):
             else:
                 db = torch.empty(M, dtype=torch.float32, device=x.device)
                 call("channel_sum", ptr(dy), ptr(db), N, M, dy.shape[2] * dy.shape[3], 0, st)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0, reflect=False, act=None, slope=0.2):
-    return _Conv2d.apply(x, w, bias, int(stride), int(pad), 1 if reflect else 0, act_code(act), float(slope))
+def conv2d(x, w, bias=None, stride=1, pad=0, reflect=False, act=None, slope=0.2, link=None):
+    return _Conv2d.apply(x, w, bias, int(stride), int(pad), 1 if reflect else 0, act_code(act), float(slope), link)
 
 
 class _ConvTranspose2d(Function):
@@ -429,6 +461,7 @@ class _ConvTranspose2d(Function):
             def wgrad(s, out, accumulate):
                 if sx is not None:
                     call("conv_set_scales", ptr(sx), ptr(sdy))
+                _wgrad_workspace(x.device, M, C, KH, KW, stride, prec)     # (the kernel sees x and dy swapped)
                 call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, accumulate, prec, s)
             if tgt is not None:
                 _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
@@ -453,7 +486,8 @@ def conv_transpose2d(x, w, bias=None, stride=1, pad=0, out_pad=0, act=None, slop
 # ----------------------------------------------------------------------------------------
 class _BatchNormTrain(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, act, slope, link=None):
+        ctx.link = link
         x = _c(x)
         N, C, H, W = x.shape
         if N * H * W <= 1:
@@ -505,7 +539,10 @@ class _BatchNormTrain(Function):
              ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
              N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
         _tag_absmax(dx, slot)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        if ctx.link is not None and dres is not None:
+            ctx.link["dres"] = dres          # the block's first convolution adds it to its input gradient in its own epilogue
+            dres = None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 class _BatchNormEval(Function):
@@ -537,8 +574,9 @@ def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, act=None
     return _BatchNormEval.apply(x, gamma, beta, running_mean, running_var, float(eps), act_code(act), float(slope))
 
 
-def batchnorm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=None, slope=0.2, residual=None):
-    y, _ = _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), act_code(act), float(slope))
+def batchnorm_train(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=None, slope=0.2, residual=None, link=None):
+    y, _ = _BatchNormTrain.apply(x, gamma, beta, residual, running_mean, running_var, float(momentum), float(eps), act_code(act), float(slope),
+                                 link if residual is not None else None)
     return y
 
 

@@ -225,7 +225,10 @@ class TrainStep:
     #: discriminator B + generator chain A  ->  109.1 ms at batch 8.  A sweep over ~90 partitions of the roles (tools/layout_search.py)
     #: found "012312" 0.4 ms faster at batch 8 but slower at batches 2, 16, 32 and 64 (45.1 vs 40.5 ms at batch 2): this one is the
     #: most even across batch sizes
-    stream_layout = "001212"
+    #: ... (round 4) with the f16x2 convolutions (65 ms steps, the kernel mix changed) the same sweep puts "012201" -- generators' weight
+    #: gradients with the identity passes | discriminators' weight gradients with generator chain B | both discriminator branches --
+    #: 3.8 % ahead: 62.4 against 64.7-65.1 ms, two runs each (profiles/r04_layout_search_f16x2.log)
+    stream_layout = "012201"
     #: ... and with a communicator, whose own streams shift the stream -> hardware-queue assignment: generator chain A on a stream of
     #: its own (111.5 -> 109.4 ms at world 1, three runs each; without a communicator this layout costs 112.9 ms)
     stream_layout_comm = "001232"

@@ -94,6 +94,20 @@ int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream
  * multiple of 4 are refused (FAOCTASR_EUNSUPPORTED): use faoctasr_absmax_bits there.                                       */
 int faoctasr_out_absmax(unsigned* slot);
 int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b);
+/* Two-pass weight-gradient reduction (precisions 2 and 3, the shapes the split kernels take): with a caller-owned, 16-byte aligned
+ * workspace of faoctasr_conv_wgrad_workspace_floats(C, M, KH, KW, stride) floats handed over for the NEXT weight-gradient call of the
+ * calling thread, every pixel range of the kernel stores its partial dW there (plain stores) and a second kernel adds them to dw
+ * in a fixed order -- instead of one fp32 atomic per partial and element.  Faster (the atomics were 29 us of a 67 us launch on the
+ * 256 -> 256 3x3 layer) and, with a step's weight gradients on one stream, bit-reproducible.  Without a workspace (or one that is
+ * too small) the call accumulates with atomics as before.  The workspace is only used between the call's two launches: calls on
+ * the same stream may share it.                                                                                            */
+int faoctasr_conv_set_workspace(float* workspace, long nfloats);
+/* y = gather(...) + residual for the NEXT gather call (conv2d_fwd / dgrad, conv_transpose2d_fwd / dgrad) of the calling thread;
+ * `residual` has the output's shape.  x + conv_block(x) (model.py:420,505) sends two gradients to x -- the skip's and the first
+ * convolution's input gradient -- and autograd adds them with an elementwise kernel (66 per train step); handing the skip's gradient
+ * to that input-gradient call adds it in the split kernels' epilogue instead (other routes: one in-place pass after the kernel). */
+int faoctasr_conv_set_residual(const float* residual);
+long faoctasr_conv_wgrad_workspace_floats(int C, int M, int KH, int KW, int stride);
 /* aten::convolution_backward, input gradient.  dx[N,C,IH,IW] from dy[N,M,OH,OW].  With
  * reflect!=0 dx is the gradient w.r.t. the PADDED input [N,C,IH+2p,IW+2p] (fold it with
  * faoctasr_reflect_pad_bwd).                                                              */

@@ -810,6 +810,116 @@ def test_absmax_slots_standalone_and_fused(fa, shape):
     assert torch.equal(y0, y)
 
 
+@pytest.mark.parametrize("case", [(8, 256, 32, 32, 256, 3, 1, 1), (2, 64, 128, 128, 64, 3, 1, 1), (2, 64, 64, 64, 64, 7, 1, 3), (2, 64, 64, 128, 128, 4, 2, 1)])
+def test_split_wgrad_two_pass_reduction_is_reproducible(fa, case):
+    """The split weight-gradient kernels with a workspace (faoctasr_conv_set_workspace): every pixel range stores its partial dW and a
+    second kernel sums them in a fixed order, so two runs give the same bits -- with fp32 atomics per partial (no workspace) they do
+    not -- and the value agrees with the atomics form to summation-order noise.  A workspace that is too small is ignored."""
+    from faoctasr._lib import call, ptr, stream_ptr
+    N, C, H, W, M, k, s, p = case
+    g = torch.Generator().manual_seed(99)
+    x = dev(torch.randn(N, C, H, W, generator=g))
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = dev(torch.randn(N, M, OH, OW, generator=g) * 1e-3)
+    sx, sdy = torch.zeros(fa.ops.SLOT_WORDS, device="cuda"), torch.zeros(fa.ops.SLOT_WORDS, device="cuda")
+    call("absmax_bits", ptr(x), x.numel(), ptr(sx), stream_ptr())
+    call("absmax_bits", ptr(dy), dy.numel(), ptr(sdy), stream_ptr())
+    need = fa._lib.load().faoctasr_conv_wgrad_workspace_floats(C, M, k, k, s)
+    assert need > 0
+    ws = torch.empty(need, device="cuda")
+
+    def run(workspace):
+        dw = torch.zeros(M, C, k, k, device="cuda")
+        call("conv_set_scales", ptr(sx), ptr(sdy))
+        if workspace is not None:
+            call("conv_set_workspace", ptr(workspace), workspace.numel())
+        call("conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), N, C, H, W, M, k, k, s, p, 0, 1, 3, stream_ptr())
+        assert fa._lib.load().faoctasr_last_route() == 15
+        torch.cuda.synchronize()
+        return dw
+
+    a, b = run(ws), run(ws)
+    assert torch.equal(a, b)
+    ref = run(None)                                             # atomics
+    assert rel_l2(a, ref) < 2e-6
+    small = run(ws[: need // 2 - 4])                            # too small: ignored, atomics
+    assert rel_l2(small, ref) < 2e-6
+    # and through the autograd op (which hands the stream's scratch buffer over): reproducible as well
+    fa.ops.conv_precision = 3
+    try:
+        outs = []
+        for _ in range(2):
+            wd = dev(torch.randn(M, C, k, k, generator=torch.Generator().manual_seed(5)) * 0.05).requires_grad_(True)
+            fa.ops.conv2d(x, wd, None, s, p, False, None, 0.2).backward(dy)
+            torch.cuda.synchronize()
+            outs.append(wd.grad.clone())
+        assert torch.equal(outs[0], outs[1])
+        assert rel_l2(outs[0], ref) < 2e-6
+    finally:
+        fa.ops.conv_precision = 0
+
+
+@pytest.mark.parametrize("precision,shape", [("f32", (2, 64, 32, 64)), ("f16x2", (2, 64, 32, 64)), ("f32_direct", (2, 16, 24, 40)), ("f16x2", (4, 256, 32, 32)),
+                                             ("f32", (2, 32, 8, 8))])
+def test_residual_block_skip_gradient_fused_into_dgrad(fa, precision, shape):
+    """x + conv_block(x) (model.py:420,505): x receives the skip's gradient and the first convolution's input gradient.  The block
+    hands the former to the latter's input-gradient call (``faoctasr_conv_set_residual``: added in the split kernels' epilogue, one
+    in-place pass behind the other kernels) instead of leaving an elementwise add to autograd.  Output, input gradient and every
+    parameter gradient against torch-CPU autograd of the same block, on the split route, the Winograd / direct f32 routes and a narrow
+    map."""
+    import torch.nn as nn
+    from faoctasr.model import ResidualBlock
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    blk = ResidualBlock(C).cuda().train()
+    ref = nn.Sequential(nn.Conv2d(C, C, 3, 1, 1, bias=False), nn.BatchNorm2d(C), nn.ReLU(), nn.Conv2d(C, C, 3, 1, 1, bias=False), nn.BatchNorm2d(C))
+    with torch.no_grad():
+        for i in (0, 3):
+            wgt = torch.randn(C, C, 3, 3, generator=g) * 0.05
+            blk.conv_block[i].weight.copy_(wgt)
+            ref[i].weight.copy_(wgt)
+        for i in (1, 4):
+            ga, be = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+            blk.conv_block[i].weight.copy_(ga); blk.conv_block[i].bias.copy_(be)
+            ref[i].weight.copy_(ga); ref[i].bias.copy_(be)
+    x = torch.randn(N, C, H, W, generator=g)
+    cot = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    pre = xr * 1.0                                              # (a non-leaf input, as inside the generator)
+    yr = torch.relu(pre + ref(pre))
+    yr.backward(cot)
+    fa.ops.conv_precision = fa.ops.PRECISIONS[precision]
+    got = {}
+    try:
+        for fused in (True, False):                             # the same block with the add left to autograd: same forward, same masks
+            fa.ops.fuse_residual_grad = fused
+            for q in blk.parameters():
+                q.grad = None
+            xd = dev(x).requires_grad_(True)
+            yd = blk(xd * 1.0, post_act="relu")
+            yd.backward(dev(cot))
+            torch.cuda.synchronize()
+            got[fused] = (yd.detach(), xd.grad, [q.grad.clone() for q in blk.parameters()])
+    finally:
+        fa.ops.conv_precision = 0
+        fa.ops.fuse_residual_grad = True
+    assert torch.equal(got[True][0], got[False][0])
+    assert rel_l2(got[True][1], got[False][1]) < 2e-6           # dgrad(dy) + dres in one epilogue == autograd's add of the two
+    for a, b in zip(got[True][2], got[False][2]):
+        assert rel_l2(a, b) < 2e-5
+    # ... and against torch-CPU autograd of the same block (a handful of ReLU masks may differ between the two arithmetics on the
+    # large shape: every such flip moves the gradients by a discrete amount, hence the looser bound there)
+    big = N * C * H * W > 500000
+    yd, dxd, _ = got[True]
+    assert rel_l2(yd, yr) < 1e-5
+    assert rel_l2(dxd, xr.grad) < (2e-3 if big else 2e-5)
+    for i in (0, 3):
+        assert rel_l2(blk.conv_block[i].weight.grad, ref[i].weight.grad) < (2e-3 if big else 5e-5)
+    for i in (1, 4):
+        assert rel_l2(blk.conv_block[i].weight.grad, ref[i].weight.grad) < (2e-3 if big else 5e-5)
+        assert rel_l2(blk.conv_block[i].bias.grad, ref[i].bias.grad) < (2e-3 if big else 5e-5)
+
+
 def test_input_pipeline_vs_oracle(fa, O):
     """fused crop + bicubic x2 + normalise (transforms_A) and crop + normalise (transforms_B) against the oracle's
     ATen restatement of train.py:129-140, including border crops (clamped bicubic taps) and a non-square source."""
