@@ -11,7 +11,7 @@ import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 _lib.load()
 torch.manual_seed(0)
-ts = faoctasr.TrainStep(device=torch.device("cuda", 0), distributed=False, precision="f32")
+ts = faoctasr.TrainStep(device=torch.device("cuda", 0), distributed=False, precision=(sys.argv[2] if len(sys.argv) > 2 else "f16x2"))
 batch = bench.make_batch(B, 256, torch.device("cuda", 0), 0)
 for _ in range(3):
     ts.step(*batch)
