@@ -76,8 +76,9 @@ KERNEL_OF = {"narrow": "igemm_nm_kernel (GEMM-shaped implicit GEMM on the packed
 #: share of the algorithmic (direct-convolution) FLOP a family really executes on the matrix pipe (split operands: three 16-bit
 #: MFMAs per fp32 product)
 EXECUTED = {"winograd": 16.0 / 36.0, "bf16x3": 3.0, "wgrad_x3": 3.0}
-#: the matrix pipe a family runs on: the exact-f32 MFMA unless listed
-PEAK = {"bf16x3": F16_MFMA_PEAK_TFLOPS, "wgrad_x3": F16_MFMA_PEAK_TFLOPS}
+#: fp32-equivalent peak of the pipe a family runs on: the exact-f32 MFMA unless listed; a split-operand product costs three 16-bit
+#: MFMAs, so the most fp32-class FLOP/s that arithmetic can deliver is the 16-bit dense peak / 3
+PEAK = {"bf16x3": F16_MFMA_PEAK_TFLOPS / 3.0, "wgrad_x3": F16_MFMA_PEAK_TFLOPS / 3.0}
 SPLIT_NAME = {"f16x2": "f16x2 (fp16 hi/lo pairs of x * 2^k, v_mfma_f32_32x32x16_f16)", "bf16x3": "bf16x3 (bf16 hi/lo pairs, v_mfma_f32_32x32x16_bf16)"}
 
 
@@ -104,10 +105,11 @@ class LaunchTimer:
             tf = d["flop"] / (d["ms"] * 1e-3) / 1e12
             ex = EXECUTED.get(fam, 1.0)
             peak = PEAK.get(fam, F32_MFMA_PEAK_TFLOPS)
+            hw_peak = F16_MFMA_PEAK_TFLOPS if fam in PEAK else F32_MFMA_PEAK_TFLOPS      # the pipe's own dense peak, for the executed FLOP
             res[fam] = {"kernel": KERNEL_OF.get(fam, fam), "launches_per_step": d["launches"] // nsteps, "ms_per_step": round(d["ms"] / nsteps, 3),
                         "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2), "gflop_per_launch": round(d["flop"] / d["launches"] / 1e9, 3),
-                        "peak_tflops": peak, "tflops_algorithmic": round(tf, 2), "frac_algorithmic": round(tf / peak, 4),
-                        "tflops_executed": round(tf * ex, 2), "frac_executed": round(tf * ex / peak, 4)}
+                        "peak_tflops": round(peak, 1), "tflops_algorithmic": round(tf, 2), "frac_algorithmic": round(tf / peak, 4),
+                        "tflops_executed": round(tf * ex, 2), "executed_pipe_peak_tflops": hw_peak, "frac_executed": round(tf * ex / hw_peak, 4)}
         return res
 
 
@@ -393,9 +395,10 @@ def main():
                 "frac": d["frac_algorithmic"], "traffic": d["hbm_bytes_per_launch_rocprof"], "family": dom,
                 "traffic_source": static_note,
                 "definition": "achieved = algorithmic (direct-convolution, fp32-equivalent) FLOP of the family's launches / their HIP-event time; "
-                              "frac_executed counts the FLOP the matrix pipe really runs (split operands: 3 16-bit MFMAs per product; Winograd: "
-                              "16/36 of the algorithmic); peak = the dense MFMA peak of the pipe the family runs on (f16/bf16 ~2500, exact f32 "
-                              "157.3 TFLOP/s at 2.4 GHz -- under this load the chip holds ~2.0 GHz, DESIGN.md 5)",
+                              "peak = the most fp32-class FLOP/s the family's arithmetic can deliver: split operands cost 3 16-bit MFMAs per product, "
+                              "so 2500 / 3 = 833.3 TFLOP/s (dense f16/bf16 MFMA peak of MI355X_MICROARCH.md / 3); exact-f32 families 157.3 TFLOP/s "
+                              "(at 2.4 GHz; under this load the chip holds ~2.0 GHz, DESIGN.md 5).  frac_executed = executed MFMA FLOP (3x, or "
+                              "16/36 for Winograd) / the pipe's own dense peak -- the same number for split families",
                 "frac_executed": d["frac_executed"], "mfma_busy_frac_rocprof": d.get("mfma_busy_frac_rocprof"),
                 "launches_per_step": d["launches_per_step"], "avg_launch_us": d["avg_launch_us"], "gflop_per_launch": d["gflop_per_launch"],
                 "ms_per_step": d["ms_per_step"]}

@@ -122,8 +122,6 @@ extern thread_local long g_wgrad_ws_floats;
 int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bias, float* y, int act, float slope, float* wpack,
              int wpack_state, hipStream_t s, PackJob* sink = nullptr);           // 1 launched, 0 not eligible, <0 error
 long wino_pack_floats_for(const IgemmGeom& f);        // 0 when not eligible
-// (experiment, not built: tools/experiments/igemm_wino64.hip -- a 64-tile, one-wave-per-SIMD form on the same packed image)
-int wino64_launch(const WinoGeom& g, const float* x, const float* wpack, const float* bias, float* y, hipStream_t s);
 
 // single-output-channel 'same' stride-1 convolution on the VALU (conv_m1.hip)
 int launch_conv_m1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int KH, int KW, int pad,

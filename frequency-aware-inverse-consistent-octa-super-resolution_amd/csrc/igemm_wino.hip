@@ -568,12 +568,6 @@ int wino_try(const IgemmGeom& f, const float* x, const float* w, const float* bi
         const int rc = check_launch("wino_pack");
         if (rc) return rc;
     }
-#ifdef WINO64              // experiment (tools/experiments/igemm_wino64.hip, built by hand next to this file): large grids on the 64-tile kernel
-    if (ksplit == 1) {
-        const int rc64 = wino64_launch(g, x, wpack, bias, y, s);
-        if (rc64 != 0) return rc64;
-    }
-#endif
     const long tiles = wino_tiles(g);
 #ifndef WINO_CUS
 #define WINO_CUS 256       // blocks of the persistent grid (experiment: fewer than the chip's 256 CUs, tools/variants.py)

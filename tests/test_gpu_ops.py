@@ -496,7 +496,7 @@ def test_conv2d_winograd_large_grids(fa, shape, act):
     """The Winograd kernel on large grids (every block walks several tiles of its persistent sequence), against the direct kernel:
     forward with bias and activation, input gradient; shapes with ragged tile rows / columns, a partial channel tile, odd width,
     a channel count that is not a multiple of the chunk, and the benchmark's 64 -> 64 layer at 256 x 256 (model.py:412-414).
-    (Written for the 64-tile experiment of tools/experiments/igemm_wino64.hip, which passed it; kept for the product kernel.)"""
+    (Written for round 3's 64-tile experiment kernel -- removed in round 4, DESIGN.md 4.1a-r3 -- which passed it; kept for the product kernel.)"""
     N, C, H, W, M = shape
     g = torch.Generator().manual_seed(90 + N + C + H + W)
     x, w, b = dev(torch.randn(N, C, H, W, generator=g)), dev(torch.randn(M, C, 3, 3, generator=g) * 0.05), dev(torch.randn(M, generator=g))

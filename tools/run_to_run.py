@@ -16,12 +16,14 @@ PAIRS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 
 
 REPRO = "--reproducible-forward" in sys.argv
+PREC = [a.split("=")[1] for a in sys.argv if a.startswith("--precision=")]
+PREC = PREC[0] if PREC else "f16x2"
 
 
 def one(overlap, a, b):
     torch.manual_seed(0)
     random.seed(1234)
-    ts = faoctasr.TrainStep(device="cuda", overlap_wgrad=overlap, reproducible_forward=REPRO)
+    ts = faoctasr.TrainStep(device="cuda", overlap_wgrad=overlap, reproducible_forward=REPRO, precision=PREC)
     L = ts.step(a, b, sync=True)
     out = (L, ts.opt_G.grad.clone(), ts.opt_D.grad.clone(), [(a.names, a.offsets, [p.numel() for p in a.params]) for a in (ts.opt_G, ts.opt_D)])
     del ts
