@@ -312,6 +312,8 @@ def main():
         faoctasr.TrainStep.eager_chain_A_forked = False
     if args.graph_variant == "side-wgrad":
         faoctasr.TrainStep.capture_side_wgrad = True
+    elif args.graph_variant == "deferred-wgrad":
+        faoctasr.TrainStep.capture_side_wgrad = "deferred"
     elif args.graph_variant == "single-chain":
         faoctasr.TrainStep.capture_two_chains = False
     if args.prio:

@@ -262,11 +262,44 @@ _wgrad_keep = {}
 wait_guard = None
 
 
+#: (captured steps, TrainStep.capture_side_wgrad == "deferred") collect the weight-gradient launches of a backward pass and enqueue
+#: them on the side stream in ONE batch when the pass is over (``end_wgrad``): one fork and one join per backward pass in the graph
+#: instead of one per weight gradient
+wgrad_defer = False
+_deferred = []
+
+
+def end_wgrad():
+    """Close a ``wgrad_stream`` scope: enqueue what ``wgrad_defer`` held back, then reset the stream."""
+    global wgrad_stream
+    side, held = wgrad_stream, list(_deferred)
+    del _deferred[:]
+    wgrad_stream = None
+    if held and side is not None:
+        seen = {side.cuda_stream}
+        for _, _, src in held + [(None, None, torch.cuda.current_stream())]:      # every stream a held launch's operands came from
+            if src.cuda_stream not in seen:
+                seen.add(src.cuda_stream)
+                if wait_guard is not None:
+                    wait_guard(side.cuda_stream, src.cuda_stream)
+                side.wait_stream(src)
+        with torch.cuda.stream(side):
+            for fn, operands, _ in held:
+                fn(side.cuda_stream)
+                _wgrad_keep.setdefault(side.cuda_stream, []).append(operands)
+    elif held:
+        for fn, _, _ in held:
+            fn(stream_ptr())
+
+
 def _enqueue_wgrad(fn, *operands):
     """``fn(stream_pointer)`` on ``wgrad_stream`` when one is set, otherwise on the current stream."""
     side = wgrad_stream
     if side is None:
         fn(stream_ptr())
+        return
+    if wgrad_defer:
+        _deferred.append((fn, operands, torch.cuda.current_stream()))
         return
     cur = torch.cuda.current_stream()
     if cur.cuda_stream != side.cuda_stream:

@@ -247,6 +247,8 @@ class TrainStep:
     #: inside a hipGraph capture: weight gradients on their side stream (True) or in line with the backward chain (False).  Every
     #: weight gradient on the side stream is a fork + join in the graph (~250 per step), which the runtime's graph executor pays for
     #: at replay: 121.3 ms per step against 115.6 in line (batch 8, MI355X; eager streams: 110.7)
+    #: "deferred": on the side stream, but the launches of one backward pass are collected and enqueued there in one batch when the
+    #: pass is over -- one fork + join per backward pass in the graph (ops.end_wgrad)
     capture_side_wgrad = False
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
@@ -344,8 +346,10 @@ class TrainStep:
         """The stream weight gradients are enqueued on, or None = on the stream of the operation that produced them.  Inside a
         hipGraph capture every cross-stream edge becomes a graph dependency the runtime synchronises at replay (experiment knob
         ``capture_side_wgrad``)."""
-        if not self.capture_side_wgrad and torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self.capture_side_wgrad and capturing:
             return None
+        ops.wgrad_defer = capturing and self.capture_side_wgrad == "deferred"
         return self._side_D if for_D else self._side
 
     # -- pieces of the loop body ---------------------------------------------------------
@@ -395,7 +399,7 @@ class TrainStep:
                 try:
                     term.backward()
                 finally:
-                    ops.wgrad_stream = None
+                    ops.end_wgrad()
             o[key].record_stream(main)
             term.record_stream(main)
             o["loss_" + key] = term.detach()
@@ -476,7 +480,7 @@ class TrainStep:
                 try:
                     term.backward()
                 finally:
-                    ops.wgrad_stream = None
+                    ops.end_wgrad()
             return ev, term.detach()
 
         def critic(net, fake, st, src):
@@ -535,7 +539,7 @@ class TrainStep:
             try:
                 chain_A.backward()
             finally:
-                ops.wgrad_stream = None
+                ops.end_wgrad()
         # ---- the caller's stream picks up the fakes (they feed the replay buffers and the discriminator phase) behind BOTH frozen
         # discriminator passes: a discriminator's update phase runs on a branch stream ordered behind the caller only, and its
         # BatchNorm running statistics must see the frozen pass first.  The loss scalars are read after the final joins.
@@ -622,7 +626,7 @@ class TrainStep:
                     L[key].backward()
                 L[key].record_stream(main)
         finally:
-            ops.wgrad_stream = None
+            ops.end_wgrad()
         return fake_A, fake_B            # alive until the branches are joined
 
     def _join_discriminator_phase(self, branches, side):
@@ -686,7 +690,7 @@ class TrainStep:
             try:
                 root.backward()
             finally:
-                ops.wgrad_stream = None
+                ops.end_wgrad()
                 if multi:                        # the identity terms' / chain A's backward ran on their own streams (BatchNorm affine gradients
                     # there), the frozen discriminator passes' input gradients on the branch streams
                     _join(torch.cuda.current_stream(self.device), (self._idt, self._aba) + tuple(self._branch))
