@@ -114,9 +114,9 @@ class LaunchTimer:
 
 
 DTYPE = {"f32": "f32 (exact-f32 MFMA: v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
-         "f16x2": "f32 tensors and fp32 accumulators; the convolutions' operands enter the matrix cores as f16x2 pairs (hi = f16(x 2^k), lo = f16(x 2^k - hi), "
+         "f16x2": "f32 (tensors and accumulators fp32; the convolutions' operands enter the matrix cores as f16x2 pairs: hi = f16(x 2^k), lo = f16(x 2^k - hi), "
                   "k from the tensor's largest magnitude; 3 v_mfma_f32_32x32x16_f16 per product) on every map >= 24 wide with >= 16 channels; "
-                  "narrow maps, 1-channel stems / head and everything that is not a convolution: exact f32",
+                  "narrow maps, 1-channel stems / head and everything that is not a convolution: exact f32; error class of the exact-f32 MFMA kernels: precision_evidence)",
          "bf16x3": "f32 tensors and fp32 accumulators; convolution operands as bf16 hi/lo pairs (3 v_mfma_f32_32x32x16_bf16 per product: 16 significant bits), f32 elsewhere"}
 #: why the f16x2 step is reported as the fp32 headline ("error at or below the exact-f32 kernels' and the step beats
 #: the f32-MFMA step"): measured, committed, and re-checked by the GPU tests named here

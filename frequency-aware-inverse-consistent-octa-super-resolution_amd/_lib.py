@@ -22,6 +22,7 @@ _SIG = {
     "conv_pack_scales": (_I, "p i p"),
     "absmax_bits": (_I, "p l p p"),
     "conv_set_scales": (_I, "pp"),
+    "conv_needs_scales": (_I, "i iiiiiiiii i i"),
     "out_absmax": (_I, "p"),
     "conv_set_workspace": (_I, "p l"),
     "conv_set_residual": (_I, "p"),

@@ -14,6 +14,10 @@ enum Route { ROUTE_NONE = 0, ROUTE_GATHER_FLAT = 1, ROUTE_PATCH = 2, ROUTE_WINOG
              ROUTE_WGRAD_FLAT = 11, ROUTE_WGRAD_PATCH = 12, ROUTE_WGRAD_S1 = 13, ROUTE_M1_WGRAD = 14, ROUTE_WGRAD_X3 = 15, ROUTE_STEM_DGRAD = 7, ROUTE_STEM_WGRAD = 16 };
 void set_route(int r);
 extern thread_local int g_no_split_k;
+// the absmax slot faoctasr_out_absmax left for this thread's next producer call (BatchNorm forward / backward, cat2_act forward):
+// taken (and cleared) by that call
+extern thread_local unsigned* g_out_absmax;
+unsigned* take_out_absmax();
 
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute is issued once per (kernel, size step), not
 // per launch: the only process-wide state of the library is this grow-only record of attributes already set

@@ -156,6 +156,10 @@ static bool stem_shape(int C, int IH, int IW, int KH, int KW, int stride, int pa
     return C >= 1 && C <= 4 && KH == 4 && KW == 4 && stride == 2 && pad == 1 && !reflect && (IH & 1) == 0 && (IW & 1) == 0 && IH >= 4 && IW >= 4;
 }
 
+bool stem_wgrad_eligible(int C, int IH, int IW, int KH, int KW, int stride, int pad, int reflect) {
+    return stem_shape(C, IH, IW, KH, KW, stride, pad, reflect);
+}
+
 bool stem_dgrad_eligible(int C, int IH, int IW, int M, int KH, int KW, int stride, int pad) {
     return stem_shape(C, IH, IW, KH, KW, stride, pad, 0) && (long)M * C * 64 <= 48 * 1024;
 }

@@ -452,6 +452,7 @@ static bool bad_ptr(const void* a, const void* b, const void* c) { return !a || 
 // the absmax slots faoctasr_conv_set_scales left for this thread's next convolution-type call: taken (and cleared) by that call
 thread_local const unsigned* g_scale_a = nullptr;
 thread_local const unsigned* g_scale_b = nullptr;
+thread_local bool g_wgrad_dry_run = false;
 thread_local float* g_wgrad_ws = nullptr;
 thread_local long g_wgrad_ws_floats = 0;
 // a weight-gradient entry takes the workspace for the duration of the call and clears it on every way out
@@ -611,6 +612,51 @@ int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b) {
     g_scale_a = slot_a;
     g_scale_b = slot_b;
     return FAOCTASR_OK;
+}
+
+// Which absmax slots the precision-3 form of a convolution-type call reads (bit 0: slot a, bit 1: slot b; 0: the call runs on a kernel
+// that needs none -- narrow map, stem, head).  kind 0..3 as faoctasr_conv_pack_job, 4 = conv2d_wgrad, 5 = conv_transpose2d_wgrad;
+// the remaining arguments exactly as the call receives them.  The answer comes from the dispatch code itself (the packing-job and
+// dry-run paths of the launchers), so a caller that asks never computes a maximum for nothing and never misses one.
+int faoctasr_conv_needs_scales(int kind, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad, int reflect, int out_pad) {
+    if (N <= 0 || C <= 0 || M <= 0 || stride <= 0 || pad < 0 || KH <= 0 || KW <= 0) return fail(FAOCTASR_EINVAL, "conv_needs_scales: bad shape");
+    IgemmGeom g;
+    const long kk = (long)KH * KW;
+    int rc, OH, OW;
+    if (kind == 0 || kind == 1 || kind == 4) { OH = (IH + 2 * pad - KH) / stride + 1; OW = (IW + 2 * pad - KW) / stride + 1; }
+    else { OH = (IH - 1) * stride - 2 * pad + KH + out_pad; OW = (IW - 1) * stride - 2 * pad + KW + out_pad; }
+    if (OH <= 0 || OW <= 0) return fail(FAOCTASR_EINVAL, "conv_needs_scales: bad shape");
+    const bool head = M == 1 && stride == 1 && !reflect && 2 * pad == KH - 1 && 2 * pad == KW - 1 && KH <= 7 && IW >= 32;
+    if (kind >= 4) {
+        struct Dry { Dry() { g_wgrad_dry_run = true; } ~Dry() { g_wgrad_dry_run = false; } } dry;
+        if (kind == 4) {
+            if (head || stem_wgrad_eligible(C, IH, IW, KH, KW, stride, pad, reflect) || OW < 24) return 0;
+            rc = launch_wgrad_x3(nullptr, nullptr, nullptr, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * kk, kk, nullptr, 1, nullptr, nullptr);
+        } else if (kind == 5) {
+            if (IW < 24) return 0;
+            rc = launch_wgrad_x3(nullptr, nullptr, nullptr, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * kk, kk, nullptr, 1, nullptr, nullptr);
+        } else {
+            return fail(FAOCTASR_EINVAL, "conv_needs_scales: unknown kind %d", kind);
+        }
+        return rc < 0 ? rc : (rc ? 3 : 0);
+    }
+    switch (kind) {
+        case 0:
+            if (head) return 0;
+            rc = geom_fwd(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, (long)C * kk, kk);
+            break;
+        case 1:
+            if (stem_dgrad_eligible(C, IH, IW, M, KH, KW, stride, pad)) return 0;
+            rc = geom_transposed(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, kk, (long)C * kk);
+            break;
+        case 2: rc = geom_transposed(g, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, kk, (long)M * kk); break;
+        default: rc = geom_fwd(g, N, M, OH, OW, C, IH, IW, KH, KW, stride, pad, 0, (long)M * kk, kk); break;
+    }
+    if (rc) return rc;
+    PackJob job{};
+    float dummy;
+    rc = split_try(g, nullptr, &dummy, nullptr, nullptr, FAOCTASR_ACT_NONE, 0.f, &dummy, 1, nullptr, &job, 1, nullptr);
+    return rc < 0 ? rc : (rc ? 1 : 0);
 }
 
 int faoctasr_conv_set_residual(const float* residual) {

@@ -131,6 +131,9 @@ int launch_conv_m1_wgrad(const float* x, const float* dy, float* dw, int N, int 
 
 // 4x4 stride-2 stems with 1..4 input channels on the VALU (conv_stem.hip): 1 launched, 0 not this shape, <0 error
 bool stem_dgrad_eligible(int C, int IH, int IW, int M, int KH, int KW, int stride, int pad);
+bool stem_wgrad_eligible(int C, int IH, int IW, int KH, int KW, int stride, int pad, int reflect);
+// set by faoctasr_conv_needs_scales: the split weight-gradient launchers then answer "would launch" (1 / 0) without launching
+extern thread_local bool g_wgrad_dry_run;
 int launch_stem_dgrad(const float* dy, const float* w, float* dx, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
                       hipStream_t s);
 int launch_stem_wgrad(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,

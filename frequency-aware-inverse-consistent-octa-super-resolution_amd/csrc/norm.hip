@@ -621,20 +621,7 @@ static int norm_bwd(const float* x, const float* dy, const float* y, const float
 
 using namespace faoctasr;
 
-// the absmax slot faoctasr_out_absmax left for this thread's next BatchNorm call: taken (and cleared) by that call
-static thread_local unsigned* g_out_absmax = nullptr;
-static unsigned* take_out_absmax() {
-    unsigned* p = g_out_absmax;
-    g_out_absmax = nullptr;
-    return p;
-}
-
 extern "C" {
-
-int faoctasr_out_absmax(unsigned* slot) {
-    g_out_absmax = slot;
-    return FAOCTASR_OK;
-}
 
 long faoctasr_bn_workspace_floats(int C) { return (long)C * BN_MAX_SPLIT * 2; }
 

@@ -20,6 +20,12 @@ int fail(int code, const char* fmt, ...) {
 }
 
 thread_local int g_route = 0;
+thread_local unsigned* g_out_absmax = nullptr;         // faoctasr_out_absmax: the slot the thread's next producer call folds max|output| into
+unsigned* take_out_absmax() {
+    unsigned* p = g_out_absmax;
+    g_out_absmax = nullptr;
+    return p;
+}
 thread_local int g_no_split_k = 0;         // set by run_gather for the duration of a call made with FAOCTASR_CONV_NO_SPLIT_K
 void set_route(int r) { g_route = r; }
 int get_route() { return g_route; }
@@ -97,15 +103,22 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 }
 
 // y[n, 0:Ca] = act(a[n]), y[n, Ca:Ca+Cb] = act(b[n]); rows of length HW (per-image blocks contiguous)
-__global__ void cat2_act_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int N, long la,
-                                    long lb, int act, float slope) {
+__global__ __launch_bounds__(256) void cat2_act_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int N, long la,
+                                    long lb, int act, float slope, unsigned* __restrict__ amax) {
     const long tot = (long)N * (la + lb);
     const long stride = (long)gridDim.x * blockDim.x;
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += stride) {
         const long n = i / (la + lb);
         const long r = i - n * (la + lb);
         const float v = r < la ? a[n * la + r] : b[n * lb + (r - la)];
-        y[i] = act_apply(v, act, slope);
+        const float o = act_apply(v, act, slope);
+        y[i] = o;
+        mx = fmaxf(mx, fabsf(o));
+    }
+    if (amax) {                                       // f16x2: max|y| into the caller's absmax slot (faoctasr_out_absmax)
+        __shared__ unsigned red[4];
+        absmax_publish_block(__builtin_bit_cast(unsigned, mx), amax, red);
     }
 }
 
@@ -549,7 +562,7 @@ int faoctasr_cat2_act_fwd(const float* a, const float* b, float* y, int N, int C
     const long tot = (long)N * (Ca + Cb) * HW;
     if (tot <= 0) return FAOCTASR_OK;
     hipLaunchKernelGGL(cat2_act_fwd_kernel, dim3(grid_for(tot, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, N, (long)Ca * HW,
-                       (long)Cb * HW, act, slope);
+                       (long)Cb * HW, act, slope, faoctasr::take_out_absmax());
     return check_launch("cat2_act_fwd");
 }
 
@@ -714,6 +727,11 @@ int faoctasr_prep_crop_resize(const unsigned char* img, const int* tops, const i
     hipLaunchKernelGGL(prep_crop_resize_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, img, tops, lefts, out, N, H,
                        W, crop, out_size, mean, 1.f / std);
     return check_launch("prep_crop_resize");
+}
+
+int faoctasr_out_absmax(unsigned* slot) {
+    faoctasr::g_out_absmax = slot;
+    return FAOCTASR_OK;
 }
 
 int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream) {

@@ -629,6 +629,7 @@ static int x3_row_go2(const float* x, const float* dy, float* dw, WgX3RowGeom& g
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    if (g_wgrad_dry_run) return 1;
     g.dw_elems = (long)g.M * g.wsm;
     float* const ws = x3_ws(g.dw_elems, g.slices);
     auto k = wgrad_x3_row_kernel<KW, S, PAD, F16>;
@@ -668,7 +669,7 @@ static int launch_wgrad_x3_row(const float* x, const float* dy, float* dw, int N
 // returns 1 when launched, 0 when the shape is left to the fp32 kernels, <0 on error.  dw zeroed / accumulating, as elsewhere.
 int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, int IH, int IW, int M, int OH, int OW, int KH, int KW,
                     int stride, int pad, int reflect, long wsm, long wsc, hipStream_t s, int f16, const unsigned* x_slot, const unsigned* dy_slot) {
-    if (f16 && (!x_slot || !dy_slot)) return fail(FAOCTASR_EINVAL, "wgrad f16x2: missing absmax slots");
+    if (f16 && !g_wgrad_dry_run && (!x_slot || !dy_slot)) return fail(FAOCTASR_EINVAL, "wgrad f16x2: missing absmax slots");
     if ((stride == 1 && KH == 7) || stride == 2)
         return launch_wgrad_x3_row(x, dy, dw, N, C, IH, IW, M, OH, OW, KH, KW, stride, pad, reflect, wsm, wsc, s, f16, x_slot, dy_slot);
     if (stride != 1 || KH != 3 || KW != 3 || pad != 1 || reflect || OH != IH || OW != IW) return 0;
@@ -684,6 +685,7 @@ int launch_wgrad_x3(const float* x, const float* dy, float* dw, int N, int C, in
     if (slices > ntiles / 4) slices = ntiles / 4 > 0 ? ntiles / 4 : 1;
     g.tiles_per_block = (int)((ntiles + slices - 1) / slices);
     g.slices = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    if (g_wgrad_dry_run) return 1;
     g.dw_elems = (long)M * wsm;
     float* const ws = x3_ws(g.dw_elems, g.slices);
     if (f16) {

@@ -80,6 +80,9 @@ def reset_scale_arenas():
     _scale_arenas.clear()
 
 
+absmax_log = None
+
+
 def _new_slot(device):
     sid = stream_ptr()
     ent = _scale_arenas.get(sid)
@@ -101,6 +104,10 @@ def absmax_slot(t):
     slot = _new_slot(t.device)
     call("absmax_bits", ptr(t), t.numel(), ptr(slot), sid)
     t._fa_absmax = (slot, t._version, sid)
+    if absmax_log is not None:                      # (diagnostics) which tensors still need a stand-alone pass, and why
+        why = "no tag" if c is None else ("version" if c[1] != t._version else "stream")
+        key = (tuple(t.shape), why)
+        absmax_log[key] = absmax_log.get(key, 0) + 1
     return slot
 
 
@@ -137,10 +144,22 @@ def _wgrad_workspace(device, C, M, KH, KW, stride, prec):
         call("conv_set_workspace", ptr(ws), ws.numel())
 
 
-def _wants_scale(C, IW, OW):
-    """Superset of the shapes the split kernels take (csrc/igemm_bf16x3.hip: >= 16 gathered channels, grid width >= 24;
-    csrc/wgrad_x3.hip: channel counts in multiples of 64, width in multiples of 32): maps narrower than that never read a slot."""
-    return conv_precision == 3 and C >= 16 and max(IW, OW) >= 24
+_scale_need = {}
+
+
+def _needs_scales(kind, dims, reflect=0, out_pad=0):
+    """Which absmax slots the precision-3 form of a convolution-type call reads (``faoctasr_conv_needs_scales``: answered by the
+    dispatch code itself): 0 = none (an exact-f32 route), 1 = slot a, 3 = both.  Cached per call signature."""
+    if conv_precision != 3:
+        return 0
+    key = (kind, dims, reflect, out_pad)
+    n = _scale_need.get(key)
+    if n is None:
+        n = _lib.load().faoctasr_conv_needs_scales(kind, *dims, reflect, out_pad)
+        if n < 0:
+            raise _lib.KernelError("conv_needs_scales: " + _lib.load().faoctasr_last_error().decode())
+        _scale_need[key] = n
+    return n
 
 
 class _PackEntry:
@@ -350,7 +369,7 @@ class _Conv2d(Function):
                                "Kernel size can't be greater than actual input size" % (IH + 2 * pad, IW + 2 * pad, KH, KW))
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
-        sx = absmax_slot(x) if _wants_scale(C, IW, OW) else None
+        sx = absmax_slot(x) if _needs_scales(0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect) else None
         if sx is not None:
             call("conv_set_scales", ptr(sx), None)
         call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
@@ -375,12 +394,15 @@ class _Conv2d(Function):
             call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
             dy = g
         dx = dw = db = None
-        sdy = absmax_slot(dy) if _wants_scale(M, IW, dy.shape[3]) else None
+        dg_dims = (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0) if reflect else (N, C, IH, IW, M, KH, KW, stride, pad)
+        need_d = _needs_scales(1, dg_dims) if ctx.needs_input_grad[0] else 0
+        need_w = _needs_scales(4, (N, C, IH, IW, M, KH, KW, stride, pad), reflect) if ctx.needs_input_grad[1] else 0
+        sdy = absmax_slot(dy) if (need_d or need_w) else None
         res = ctx.link.pop("dres", None) if ctx.link is not None else None
         if res is not None and not ctx.needs_input_grad[0]:
             raise _lib.KernelError("a residual link left a skip gradient for a convolution whose input needs no gradient")
         if ctx.needs_input_grad[0]:
-            if sdy is not None:
+            if need_d:
                 call("conv_set_scales", ptr(sdy), None)
             if res is not None and not reflect:
                 call("conv_set_residual", ptr(_c(res)))
@@ -404,20 +426,20 @@ class _Conv2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             prec = conv_precision
-            sx = ctx.sx
-            if prec == 3 and sdy is not None and sx is None:
-                sx = absmax_slot(x)
-            if prec == 3 and (sx is None or sdy is None):
-                prec = 0                               # a map too narrow for the split kernels: the exact-f32 kernels, no slots
-                sx = sdy = None
+            sx = None
+            if need_w:
+                sx = ctx.sx if ctx.sx is not None else absmax_slot(x)
+            elif prec == 3:
+                prec = 0                               # a shape the split weight-gradient kernels leave to the exact-f32 ones: no slots
+            sdw = sdy if need_w else None
 
             def wgrad(s, out, accumulate):
                 if sx is not None:
-                    call("conv_set_scales", ptr(sx), ptr(sdy))
+                    call("conv_set_scales", ptr(sx), ptr(sdw))
                 _wgrad_workspace(x.device, C, M, KH, KW, stride, prec)
                 call("conv2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, prec, s)
             if tgt is not None:
-                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
+                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdw)
             else:
                 wgrad(st, dw, 0)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
@@ -445,7 +467,7 @@ class _ConvTranspose2d(Function):
         OH, OW = (IH - 1) * stride - 2 * pad + KH + out_pad, (IW - 1) * stride - 2 * pad + KW + out_pad
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
-        sx = absmax_slot(x) if _wants_scale(C, IW, OW) else None
+        sx = absmax_slot(x) if _needs_scales(2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad) else None
         if sx is not None:
             call("conv_set_scales", ptr(sx), None)
         ctx.sx = sx
@@ -470,11 +492,13 @@ class _ConvTranspose2d(Function):
             call("act_bwd", ptr(dy), ptr(y), ptr(g), dy.numel(), act, slope, st)
             dy = g
         dx = dw = db = None
-        sdy = absmax_slot(dy) if _wants_scale(M, IW, dy.shape[3]) else None
+        need_d = _needs_scales(3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad) if ctx.needs_input_grad[0] else 0
+        need_w = _needs_scales(5, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad) if ctx.needs_input_grad[1] else 0
+        sdy = absmax_slot(dy) if (need_d or need_w) else None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp, wst, ent = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
-            if sdy is not None:
+            if need_d:
                 call("conv_set_scales", ptr(sdy), None)
             call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
                  conv_precision, st)
@@ -484,20 +508,20 @@ class _ConvTranspose2d(Function):
             if tgt is None:
                 dw = torch.empty_like(w)
             prec = conv_precision
-            sx = ctx.sx
-            if prec == 3 and sdy is not None and sx is None:
-                sx = absmax_slot(x)
-            if prec == 3 and (sx is None or sdy is None):
+            sx = None
+            if need_w:
+                sx = ctx.sx if ctx.sx is not None else absmax_slot(x)
+            elif prec == 3:
                 prec = 0
-                sx = sdy = None
+            sdw = sdy if need_w else None
 
             def wgrad(s, out, accumulate):
                 if sx is not None:
-                    call("conv_set_scales", ptr(sx), ptr(sdy))
+                    call("conv_set_scales", ptr(sx), ptr(sdw))
                 _wgrad_workspace(x.device, M, C, KH, KW, stride, prec)     # (the kernel sees x and dy swapped)
                 call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, accumulate, prec, s)
             if tgt is not None:
-                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdy)
+                _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdw)
             else:
                 wgrad(st, dw, 0)
         if ctx.b_ref is not None and ctx.needs_input_grad[2]:
@@ -679,7 +703,9 @@ class _Cat2Act(Function):
         N, Ca, H, W = a.shape
         Cb = b.shape[1]
         y = torch.empty((N, Ca + Cb, H, W), dtype=torch.float32, device=a.device)
+        slot = _producer_slot(a, Ca + Cb, H, W)
         call("cat2_act_fwd", ptr(a), ptr(b), ptr(y), N, Ca, Cb, H * W, act, slope, stream_ptr())
+        _tag_absmax(y, slot)
         ctx.save_for_backward(y if act else None)
         ctx.cfg = (act, slope, Ca, Cb)
         return y

@@ -88,12 +88,17 @@ int faoctasr_conv_pack_scales(const void* jobs_dev, int njobs, faoctasr_stream_t
  * the split kernels do not take (maps narrower than 24, fewer than 16 channels) silently run on the exact-f32 kernels. */
 #define FAOCTASR_ABSMAX_SLOT_WORDS 128
 int faoctasr_absmax_bits(const float* x, long n, unsigned* slot, faoctasr_stream_t stream);
-/* The producer's side of the same slot: the NEXT faoctasr_batchnorm_train_fwd (its y) / faoctasr_batchnorm_train_bwd (its dx) call
- * of the calling thread folds the largest magnitude of its output into `slot` (zeroed by the caller) in its own store loop, so
+/* The producer's side of the same slot: the NEXT faoctasr_batchnorm_train_fwd (its y) / faoctasr_batchnorm_train_bwd (its dx) /
+ * faoctasr_cat2_act_fwd (its y) call of the calling thread folds the largest magnitude of its output into `slot` (zeroed by the caller) in its own store loop, so
  * the convolution that reads that tensor needs no separate faoctasr_absmax_bits pass over it.  Map sizes (H*W) that are not a
  * multiple of 4 are refused (FAOCTASR_EUNSUPPORTED): use faoctasr_absmax_bits there.                                       */
 int faoctasr_out_absmax(unsigned* slot);
 int faoctasr_conv_set_scales(const unsigned* slot_a, const unsigned* slot_b);
+/* Which slots the precision-3 form of a call reads: bit 0 = slot a, bit 1 = slot b, 0 = none (the shape runs on an exact-f32
+ * kernel).  kind 0..3 as faoctasr_conv_pack_job (conv2d_fwd, conv2d_dgrad, conv_transpose2d_fwd, conv_transpose2d_dgrad),
+ * 4 = conv2d_wgrad, 5 = conv_transpose2d_wgrad; the other arguments exactly as that call receives them.                      */
+int faoctasr_conv_needs_scales(int kind, int N, int C, int IH, int IW, int M, int KH, int KW, int stride, int pad,
+                               int reflect, int out_pad);
 /* Two-pass weight-gradient reduction (precisions 2 and 3, the shapes the split kernels take): with a caller-owned, 16-byte aligned
  * workspace of faoctasr_conv_wgrad_workspace_floats(C, M, KH, KW, stride) floats handed over for the NEXT weight-gradient call of the
  * calling thread, every pixel range of the kernel stores its partial dW there (plain stores) and a second kernel adds them to dw
