@@ -649,7 +649,10 @@ class TrainStep:
         packed = plan is not None and plan.run()        # every packed-weight image of a step of this shape in one launch
         if not packed:
             self._pack_plans.pop(plan_key, None)
-            ops.clear_touched()                         # ... so that the plan built after this step holds exactly what it used
+        # a plan built after this step (a pack miss: new shape, or a weight that moved) then holds exactly the images THIS step used --
+        # cleared every step, not only on steps without a plan: otherwise the images of other batch shapes and of evaluation calls
+        # touched since the last plan-less step would be swept into the rebuilt plan and repacked on every step
+        ops.clear_touched()
         # below ~2 x 256^2 pixels per batch the step is bound by the host's enqueue rate, and the extra events / stream switches
         # of the schedule cost more than the concurrency returns (batch 1 at 256^2: 41.8 vs 39.3 ms; batch 2: 48.3 vs 52.8)
         # ... a CAPTURED step has no host in its way: there the schedule pays at every size (batch 1: 29.9 against 35.4 ms per replay)

@@ -365,6 +365,15 @@ def test_graph_captured_step_matches_eager_and_golden(fa, O):
     for k in sd_e:
         if k.endswith("num_batches_tracked"):
             assert int(sd_e[k]) == int(sd_g[k]), k
+    # the discriminators' BatchNorm running statistics: their frozen pass (generator phase) and their update phase run on different
+    # streams and both do a plain read-modify-write of running_mean / running_var -- the schedule orders them; a lost
+    # update would remove one of the nine momentum-weighted contributions (>= 10 % of the value); three steps of trajectory drift between
+    # the two runs move the statistics by ~2e-3
+    for key in ("D_A", "D_B"):
+        sd_e, sd_g = n[key].state_dict(), n2[key].state_dict()
+        for k in sd_e:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert float((sd_e[k] - sd_g[k]).abs().max()) <= 3e-2 * float(sd_e[k].abs().max()) + 1e-6, (key, k)
     # replay histories hold the same images (up to step-to-step rounding drift)
     assert len(ts.fake_A_buffer.data) == len(eager.fake_A_buffer.data)
     close(ts.fake_A_buffer.data[0], eager.fake_A_buffer.data[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
@@ -478,6 +487,41 @@ def test_trailing_partial_batch_under_stream_schedule(fa, O):
             assert L1[k] == pytest.approx(v, rel=2e-5, abs=1e-7), (i, k, L1[k], v)
         for x, y in ((g1, g0), (d1, d0)):
             assert float((x.double() - y.double()).norm() / y.double().norm()) < 1e-4, i
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_capturable_chain_arrangement_eager_vs_single_stream(fa, O, precision):
+    """the arrangement of the two-chain schedule that a hipGraph capture uses (chain A on the caller's stream,
+    ``eager_chain_A_forked = False``) was only ever exercised through the captured graph.  Here it runs EAGERLY, multi-stream, against
+    the single-stream step: lr = 0 and ``reproducible_forward`` as in the trailing-batch test, two steps; losses to 2e-5, gradient
+    arenas to 1e-4, and every BatchNorm buffer of all four networks (running statistics are read-modify-written by each pass: a missing
+    event between two passes of one network shows as a lost update)."""
+    batches = [O.synthetic_batch(4, 192, seed=70), O.synthetic_batch(4, 192, seed=71)]
+    runs = {}
+    keep = fa.TrainStep.eager_chain_A_forked
+    try:
+        for overlap in (False, True):
+            fa.TrainStep.eager_chain_A_forked = False
+            random.seed(1234)
+            n = build_nets(fa, O)
+            ts = fa.TrainStep(n["A2B"], n["B2A"], n["D_A"], n["D_B"], lr=0.0, overlap_wgrad=overlap, reproducible_forward=True, precision=precision)
+            ts.overlap_min_pixels = 0
+            out = []
+            for a, b in batches:
+                L = ts.step(a.cuda(), b.cuda(), sync=True)
+                out.append((L, ts.opt_G.grad.clone(), ts.opt_D.grad.clone()))
+            bufs = {k + "." + name: v.clone() for k, net in n.items() for name, v in net.state_dict().items() if "running_" in name}
+            runs[overlap] = (out, bufs)
+            del ts
+    finally:
+        fa.TrainStep.eager_chain_A_forked = keep
+    for i, ((L1, g1, d1), (L0, g0, d0)) in enumerate(zip(runs[True][0], runs[False][0])):
+        for k, v in L0.items():
+            assert L1[k] == pytest.approx(v, rel=2e-5, abs=1e-7), (i, k, L1[k], v)
+        for x, y in ((g1, g0), (d1, d0)):
+            assert float((x.double() - y.double()).norm() / y.double().norm()) < 1e-4, i
+    for k, v in runs[False][1].items():
+        assert float((runs[True][1][k] - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-7, k
 
 
 @pytest.mark.gpu
