@@ -684,7 +684,8 @@ def test_conv2d_f16x2(fa, case):
     class -- measured 0.7x .. 1.4x of their error per layer and operand (profiles/r04_f16x2_layer_errors.txt; the f32 kernels
     split their reduction over chunks and blocks, which is worth about as much as the split's 3-per-16 accumulator roundings), both
     2e-7 .. 1e-6 against fp64 and ~15x below bf16x3.  The cotangent is ~1e-4 with a heavy tail, like a real gradient: without
-    the per-tensor scale its lo halves would be fp16 subnormals."""
+    the per-tensor scale its lo halves would be fp16 subnormals.  (The assertion allows 2x + 5e-8: the f32 kernels' own error moves
+    with the order of their atomics from run to run; a fall back to 16-bit operands would be 15x.)"""
     N, C, H, W, M, k, s, p, reflect, bias, act = case
     g = torch.Generator().manual_seed(4242)
     x = torch.randn(N, C, H, W, generator=g)
@@ -706,7 +707,7 @@ def test_conv2d_f16x2(fa, case):
         err[prec] = (rel_l2(out, ref), rel_l2(xd.grad, dx64), rel_l2(wd.grad, dw64))
     for what, e32, e16 in zip(("y", "dx", "dw"), err[1], err[3]):
         print("f16x2-vs-f32 %s %s f32 %.3e f16x2 %.3e ratio %.2f" % (case, what, e32, e16, e16 / e32))
-        assert e16 <= 1.6 * e32 + 5e-8, (case, what, e32, e16)
+        assert e16 <= 2.0 * e32 + 5e-8, (case, what, e32, e16)
         assert e16 < 2e-6, (case, what, e16)
     # the forward really ran on the split kernel (the route is per calling thread: ask the C ABI directly)
     from faoctasr._lib import call, ptr, stream_ptr
@@ -766,7 +767,7 @@ def test_conv_transpose2d_f16x2(fa, case):
         err[prec] = (rel_l2(out, ref), rel_l2(xd.grad, xr.grad), rel_l2(wd.grad, wr.grad))
     for what, e32, e16 in zip(("y", "dx", "dw"), err[1], err[3]):
         print("f16x2-vs-f32 convT %s %s f32 %.3e f16x2 %.3e ratio %.2f" % (case, what, e32, e16, e16 / e32))
-        assert e16 <= 1.6 * e32 + 5e-8, (case, what, e32, e16)
+        assert e16 <= 2.0 * e32 + 5e-8, (case, what, e32, e16)
 
 
 @pytest.mark.parametrize("shape", [(4, 32, 64, 64), (2, 64, 24, 40), (8, 16, 128, 128)])
