@@ -31,7 +31,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     allp = [p for p in partitions(6, 4) if len(set(p)) >= 2]
-    pick = ["001212", "001232", "012312"] + random.sample(allp, n)
+    pick = ["012201", "001212", "012101", "012221", "012102"] + random.sample(allp, n)
     res = []
     for p in pick:
         ms = run(p)
