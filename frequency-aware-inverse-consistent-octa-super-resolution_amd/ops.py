@@ -112,13 +112,20 @@ def absmax_slot(t):
 
 
 def _producer_slot(x, C, H, W):
-    """A fresh absmax slot handed to the NEXT BatchNorm call (``faoctasr_out_absmax``) when its output can feed a split-precision
-    convolution (>= 16 channels, a map >= 24 wide, H*W a multiple of 4); None otherwise."""
+    """A fresh absmax slot for a producer call (BatchNorm forward / backward, cat2_act forward) whose output can feed a
+    split-precision convolution (>= 16 channels, a map >= 24 wide, H*W a multiple of 4); None otherwise.  ``_producer_call`` hands it
+    over."""
     if conv_precision != 3 or C < 16 or W < 24 or (H * W) & 3:
         return None
-    slot = _new_slot(x.device)
-    call("out_absmax", ptr(slot))
-    return slot
+    return _new_slot(x.device)
+
+
+def _producer_call(name, args, slot):
+    """A producer call with ``faoctasr_out_absmax(slot)`` set immediately before it (``args`` are already evaluated: nothing that can
+    raise sits between the setter and its consumer)."""
+    if slot is not None:
+        call("out_absmax", ptr(slot))
+    call(name, *args)
 
 
 def _tag_absmax(t, slot):
@@ -142,6 +149,19 @@ def _wgrad_workspace(device, C, M, KH, KW, stride, prec):
     if n > 0:
         ws = _lib.workspace(device, n + (1 << 16), tag="wgrad")
         call("conv_set_workspace", ptr(ws), ws.numel())
+
+
+def _conv_call(name, args, slot_a=None, slot_b=None, residual=None):
+    """One convolution-type C call with its hand-over state (``faoctasr_conv_set_scales`` / ``faoctasr_conv_set_residual``: thread-local,
+    consumed by the next call) set IMMEDIATELY before it: nothing that can raise -- an allocation, a pack, a pointer check -- sits
+    between a setter and the call that consumes it, so a failed step cannot leave a slot or a residual pointer behind for an unrelated
+    later call."""
+    pa, pb, pr = ptr(slot_a), ptr(slot_b), ptr(residual)
+    if pa is not None:
+        call("conv_set_scales", pa, pb)
+    if pr is not None:
+        call("conv_set_residual", pr)
+    call(name, *args)
 
 
 _scale_need = {}
@@ -370,10 +390,8 @@ class _Conv2d(Function):
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect)
         sx = absmax_slot(x) if _needs_scales(0, (N, C, IH, IW, M, KH, KW, stride, pad), reflect) else None
-        if sx is not None:
-            call("conv_set_scales", ptr(sx), None)
-        call("conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
-             conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
+        _conv_call("conv2d_fwd", (ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, reflect, act, slope, ptr(wp), wst,
+                                  conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr()), sx)
         _packed(ent, wst)
         ctx.sx = sx
         ctx.save_for_backward(x, w, y if act else None)
@@ -402,24 +420,23 @@ class _Conv2d(Function):
         if res is not None and not ctx.needs_input_grad[0]:
             raise _lib.KernelError("a residual link left a skip gradient for a convolution whose input needs no gradient")
         if ctx.needs_input_grad[0]:
-            if need_d:
-                call("conv_set_scales", ptr(sdy), None)
-            if res is not None and not reflect:
-                call("conv_set_residual", ptr(_c(res)))
+            sd = sdy if need_d else None
+            if res is not None:
+                res = _c(res)
             if reflect:
                 dxp = torch.empty((N, C, IH + 2 * pad, IW + 2 * pad), dtype=torch.float32, device=x.device)
                 wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0))
-                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
-                     conv_precision, st)
+                _conv_call("conv2d_dgrad", (ptr(dy), ptr(w), ptr(dxp), N, C, IH + 2 * pad, IW + 2 * pad, M, KH, KW, stride, 0, ptr(wp), wst,
+                                            conv_precision, st), sd)
                 _packed(ent, wst)
                 dx = torch.empty_like(x)
                 call("reflect_pad_bwd", ptr(dxp), ptr(dx), N * C, IH, IW, pad, st)
                 if res is not None:
-                    call("axpby", ptr(dx), ptr(_c(res)), ptr(dx), dx.numel(), 1.0, 1.0, st)
+                    call("axpby", ptr(dx), ptr(res), ptr(dx), dx.numel(), 1.0, 1.0, st)
             else:
                 dx = torch.empty_like(x)
                 wp, wst, ent = _wpack(ctx.w_ref, 1, (N, C, IH, IW, M, KH, KW, stride, pad))
-                call("conv2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st)
+                _conv_call("conv2d_dgrad", (ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, ptr(wp), wst, conv_precision, st), sd, None, res)
                 _packed(ent, wst)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
@@ -434,10 +451,8 @@ class _Conv2d(Function):
             sdw = sdy if need_w else None
 
             def wgrad(s, out, accumulate):
-                if sx is not None:
-                    call("conv_set_scales", ptr(sx), ptr(sdw))
                 _wgrad_workspace(x.device, C, M, KH, KW, stride, prec)
-                call("conv2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, prec, s)
+                _conv_call("conv2d_wgrad", (ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, reflect, accumulate, prec, s), sx, sdw)
             if tgt is not None:
                 _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdw)
             else:
@@ -468,11 +483,9 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, M, OH, OW), dtype=torch.float32, device=x.device)
         wp, wst, ent = _wpack(w, 2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
         sx = absmax_slot(x) if _needs_scales(2, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad) else None
-        if sx is not None:
-            call("conv_set_scales", ptr(sx), None)
         ctx.sx = sx
-        call("conv_transpose2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
-             ptr(wp), wst, conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr())
+        _conv_call("conv_transpose2d_fwd", (ptr(x), ptr(w), ptr(bias), ptr(y), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, act, slope,
+                                            ptr(wp), wst, conv_precision | (NO_SPLIT_K if reproducible_forward else 0), stream_ptr()), sx)
         _packed(ent, wst)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.w_ref, ctx.b_ref = w, bias
@@ -498,10 +511,8 @@ class _ConvTranspose2d(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wp, wst, ent = _wpack(ctx.w_ref, 3, (N, C, IH, IW, M, KH, KW, stride, pad), 0, out_pad)
-            if need_d:
-                call("conv_set_scales", ptr(sdy), None)
-            call("conv_transpose2d_dgrad", ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
-                 conv_precision, st)
+            _conv_call("conv_transpose2d_dgrad", (ptr(dy), ptr(w), ptr(dx), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, ptr(wp), wst,
+                                                  conv_precision, st), sdy if need_d else None)
             _packed(ent, wst)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_ref)
@@ -516,10 +527,9 @@ class _ConvTranspose2d(Function):
             sdw = sdy if need_w else None
 
             def wgrad(s, out, accumulate):
-                if sx is not None:
-                    call("conv_set_scales", ptr(sx), ptr(sdw))
                 _wgrad_workspace(x.device, M, C, KH, KW, stride, prec)     # (the kernel sees x and dy swapped)
-                call("conv_transpose2d_wgrad", ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, accumulate, prec, s)
+                _conv_call("conv_transpose2d_wgrad", (ptr(x), ptr(dy), ptr(out), N, C, IH, IW, M, KH, KW, stride, pad, out_pad, accumulate, prec, s),
+                           sx, sdw)
             if tgt is not None:
                 _enqueue_wgrad(lambda s: wgrad(s, tgt, 1), x, dy, sx, sdw)
             else:
@@ -556,8 +566,8 @@ class _BatchNormTrain(Function):
         ws = _lib.workspace(x.device, C * 128)
         sp = stats.data_ptr()                   # (row views cost ~3 us each on the host: 243 calls per step)
         slot = _producer_slot(x, C, H, W)       # f16x2: the output's largest magnitude comes out of this kernel's store loop
-        call("batchnorm_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), sp, sp + 4 * C,
-             ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr())
+        _producer_call("batchnorm_train_fwd", (ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), sp, sp + 4 * C,
+                                               ptr(running_mean), ptr(running_var), N, C, H * W, eps, momentum, act, slope, ptr(ws), stream_ptr()), slot)
         # the backward takes the ReLU / LeakyReLU mask from x when there was no residual (faoctasr.h): y is then not kept by this node
         need_y = act == ACT_TANH or (act and residual is not None)
         ctx.save_for_backward(x, gamma, stats, y if need_y else None, beta if (act and not need_y) else None)
@@ -592,9 +602,10 @@ class _BatchNormTrain(Function):
         ws = _lib.workspace(x.device, C * 128)
         sp = stats.data_ptr()
         slot = _producer_slot(x, C, H, W)       # f16x2: dx is the dY of the convolution in front of this layer
-        call("batchnorm_train_bwd", ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), sp, sp + 4 * C, ptr(dx),
-             ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta), ptr(dres) if (dres is not None and act) else None,
-             N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr())
+        _producer_call("batchnorm_train_bwd", (ptr(x), ptr(dy), ptr(y), ptr(gamma), ptr(beta), sp, sp + 4 * C, ptr(dx),
+                                               ptr(tg if accumulate else dgamma), ptr(tb if accumulate else dbeta),
+                                               ptr(dres) if (dres is not None and act) else None,
+                                               N, C, H * W, act, slope, accumulate, ptr(ws), stream_ptr()), slot)
         _tag_absmax(dx, slot)
         if ctx.link is not None and dres is not None:
             ctx.link["dres"] = dres          # the block's first convolution adds it to its input gradient in its own epilogue
@@ -704,7 +715,7 @@ class _Cat2Act(Function):
         Cb = b.shape[1]
         y = torch.empty((N, Ca + Cb, H, W), dtype=torch.float32, device=a.device)
         slot = _producer_slot(a, Ca + Cb, H, W)
-        call("cat2_act_fwd", ptr(a), ptr(b), ptr(y), N, Ca, Cb, H * W, act, slope, stream_ptr())
+        _producer_call("cat2_act_fwd", (ptr(a), ptr(b), ptr(y), N, Ca, Cb, H * W, act, slope, stream_ptr()), slot)
         _tag_absmax(y, slot)
         ctx.save_for_backward(y if act else None)
         ctx.cfg = (act, slope, Ca, Cb)
