@@ -686,6 +686,13 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             const float* const rimg = res ? res + (long)cn * g.M * (long)ohw : nullptr;
             const bool full_m = m0 + SP_MT <= g.M;
             if (wide) {
+                // (Round 4, measured and not kept: swapping the MFMA operands -- (patch, weights) instead of (weights, patch), free because both
+                // fragments have the same register layout -- makes an accumulator register quad 4 consecutive PIXELS of one channel, i.e. 16
+                // contiguous output bytes, and the epilogue 16 global_store_dwordx4 per lane with no LDS transpose and no staging buffer
+                // (216 -> 188 registers).  Correct (all split-kernel tests), and slower: 64 -> 64 @256^2 123.3 -> 129.0 us, 64 -> 128 @128^2
+                // 67.6 -> 70.1 -- such a store instruction touches 32 lines with 32 bytes each instead of 8 whole lines, and the CU's memory
+                // path charges per line; the ablations of the same round say where the time is instead: without ANY global load the layer
+                // still takes 97 us of 133, i.e. the consumers' own loop + epilogue + barriers are 1.7x the 56 us of MFMA work.)
                 // 32 x 32 accumulator tile -> the wave's 4 KiB of staging (a lane holds ONE pixel of 16 rows) -> a lane reads 4
                 // pixels of a row back: 4 dwordx4 stores per tile, each 8 rows x 128 B, instead of 16 dword stores of 2 x 128 B.
                 // The stores of a wave drain at its memory-instruction rate (s_memtime trace: 64 of them = the 8100-cycle tile
