@@ -7,7 +7,7 @@ sys.path.insert(0, "/root/repo")
 import faoctasr
 from faoctasr import ops
 lib = faoctasr._lib.load()
-ops.conv_precision = ops.PRECISIONS["bf16x3"]
+ops.conv_precision = ops.PRECISIONS[__import__("os").environ.get("FAOCTASR_PRECISION", "f16x2")]
 C, M, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (64, 64, 256)))
 x = torch.randn(8, C, H, H, device="cuda"); w = torch.randn(M, C, 3, 3, device="cuda") * 0.05
 with torch.no_grad():
