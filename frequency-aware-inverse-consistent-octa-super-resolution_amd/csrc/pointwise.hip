@@ -517,7 +517,7 @@ using namespace faoctasr;
 
 extern "C" {
 
-int faoctasr_version(void) { return 210; }
+int faoctasr_version(void) { return 400; }      // round 4: f16x2 (precision 3), absmax slots, two-pass weight-gradient reduction, fused residual
 const char* faoctasr_last_error(void) { return err_buf(); }
 int faoctasr_last_route(void) { return faoctasr::get_route(); }
 
