@@ -567,6 +567,10 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                 const unsigned Ah = lds0 + A_base + (abuf * 2 + 0) * a_bytes + a_lane, Al = Ah + a_bytes;
                 const unsigned Ph = lds0 + P_base + (pbuf * 2 + 0) * p_bytes + b_lane, Pl = Ph + p_bytes;
                 bf16x8 a0[MI][2], b0[NI][2], a1[MI][2], b1[NI][2];
+                // (Round 4, measured and not kept: the reads issued in the order of their first use -- the lo*hi term's set, then the hi*lo
+                // term's -- with one counted wait per term instead of one lgkmcnt(0) per step, so that the youngest read has 8 MFMAs of cover
+                // instead of 4: correct, and within the noise on every layer (64 -> 64 @256^2 122.0 -> 120.9 us, 256 -> 256 @32^2 56.6 -> 58.4, step
+                // 123.0-125.5 -> 122.8-125.8 img/s): the 20 % this loop runs over its MFMAs is not exposed LDS latency.)
                 // One tap step = 3 MI NI MFMAs on the CURRENT fragment set with the 2 (MI + NI) ds_read_b128 of the NEXT tap's set
                 // issued one per MFMA gap (round 3; the round-1 loop issued the eight reads in a bunch before the twelve MFMAs and
                 // the matrix pipe idled for ~170 of every 560 cycles: s_memtime trace).  Terms outermost, so that
