@@ -307,7 +307,7 @@ def main():
     if args.graph_only:
         args.no_roofline = args.no_alt = args.no_cpu_baseline = True
     if args.layout:
-        faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = args.layout
+        faoctasr.TrainStep.stream_layout = faoctasr.TrainStep.stream_layout_comm = faoctasr.TrainStep.stream_layout_f32 = args.layout
     if args.eager_chain_a_on_caller:
         faoctasr.TrainStep.eager_chain_A_forked = False
     if args.graph_variant == "side-wgrad":
@@ -421,18 +421,19 @@ def main():
         for prec in ("f32", "bf16x3", "f16x2"):
             if prec == args.precision:
                 continue
-            ts.precision = prec
-            for _ in range(2):
-                ts.step(real_A, real_B)
+            # a step of its own: the stream layout is chosen per precision when the step is built (TrainStep.stream_layout_f32)
+            alt = faoctasr.TrainStep(device=device, distributed=False, precision=prec, overlap_wgrad=not args.no_overlap)
+            for _ in range(3):
+                alt.step(real_A, real_B)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                ts.step(real_A, real_B)
+                alt.step(real_A, real_B)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
+            del alt
             key, note = notes[prec]
             extra[key] = {"value": round(B * args.steps / dt, 3), "unit": "images/s", "ms_per_step": round(1e3 * dt / args.steps, 3), "dtype": note}
-        ts.precision = args.precision
     # the same step as ONE captured hipGraph (SURVEY 8f-1 / BASELINE config 5): reported beside the headline, never as it
     # (data-parallel: every rank captures and replays in lockstep, RCCL's kernels are graph nodes -- opt-in with --ddp-graph)
     graph_note = "whole G+D step replayed as one hipGraph: device-side replay buffer, AdamW scalars in device memory"

@@ -229,6 +229,9 @@ class TrainStep:
     #: gradients with the identity passes | discriminators' weight gradients with generator chain B | both discriminator branches --
     #: 3.8 % ahead: 62.4 against 64.7-65.1 ms, two runs each (profiles/r04_layout_search_f16x2.log)
     stream_layout = "012201"
+    #: ... the exact-f32 kernels (``precision`` "f32" / "f32_direct": 110 ms steps, another kernel mix) keep round 3's layout: 73.2-73.5 img/s
+    #: with it against 71.8-72.1 with "012201"
+    stream_layout_f32 = "001212"
     #: ... and with a communicator, whose own streams shift the stream -> hardware-queue assignment: generator chain A on a stream of
     #: its own (111.5 -> 109.4 ms at world 1, three runs each; without a communicator this layout costs 112.9 ms)
     stream_layout_comm = "001232"
@@ -296,7 +299,7 @@ class TrainStep:
         self._side = self._side_D = self._idt = self._aba = self._branch = None
         if dev.type == "cuda":
             made = {}
-            layout = self.stream_layout_comm if self.distributed else self.stream_layout
+            layout = self.stream_layout_comm if self.distributed else (self.stream_layout_f32 if precision in ("f32", "f32_direct") else self.stream_layout)
             prio = self.stream_priorities
             roles = [made.setdefault(ch, torch.cuda.Stream(device=dev, priority=int(prio[int(ch)]) if prio else 0)) for ch in layout]
             self._side, self._side_D, bA, bB, self._idt, self._aba = roles
