@@ -128,6 +128,9 @@ PRECISION_EVIDENCE = {
     "step_error_vs_fp64_oracle": "192^2 batch 2, step 0, full gradient of each network vs an fp64 run of the oracle: f16x2 4.3e-3 / 3.1e-3 / 3.2e-6 / 3.0e-4 "
                                  "against exact-f32 4.6e-3 / 3.6e-3 / 3.4e-6 / 5.1e-3 (A2B / B2A / D_A / D_B) -- profiles/r04_step_error_vs_fp64.txt, "
                                  "tests/test_gpu_step.py::test_step_gradients_vs_fp64_oracle_f16x2_beside_f32",
+    "ten_step_trajectory": "ten consecutive steps from one initial state, fp32 CPU oracle vs exact-f32 HIP vs f16x2 HIP: both HIP runs drift from the oracle at "
+                           "the same rate (1e-7 at step 0, 1e-4 at step 2, ~1.3e-2 at steps 7-9; worst deviation f16x2 1.7e-2, exact-f32 1.3e-2) -- "
+                           "profiles/r04_ten_step_trajectory.txt, tests/test_gpu_step.py::test_ten_step_trajectory_f16x2_tracks_the_oracle_like_exact_f32",
     "reference_fixtures": "same bars as the exact-f32 step against the reference's fixtures (losses 1e-3, gradient norms 2e-3, 3 configs, all steps): "
                           "tests/test_gpu_step.py::test_train_step_f16x2_precision",
     "bare_mfma_probe": "32x32 tile, K = 576 .. 65536: f16x2 2.7e-7 .. 3.6e-6 vs the fp32 FMA chain / v_mfma_f32_32x32x2_f32 3.2e-7 .. 3.4e-6 -- "
