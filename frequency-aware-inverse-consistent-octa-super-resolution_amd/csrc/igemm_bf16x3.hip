@@ -551,6 +551,8 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         }
     };
 
+    float inv = 1.f;                                                    // f16x2: the operands were x * s_x and w * s_w
+    if constexpr (F16) inv = f16x2_inv_scale(absmax_read(x_slot)) * f16x2_inv_scale(split_w_absmax(w_slot));
     long tile = blockIdx.x;
     asm volatile("s_barrier" ::: "memory");                             // first patch + first weight slab staged by the producers
     int slab = 0, pcount = 0;
@@ -639,8 +641,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             int cn, cty, ctx;
             tile_coords(tile, cn, cty, ctx);
             const int mrow0 = m0 + 4 * lh;
-            if constexpr (F16) {                                         // the operands were x * s_x and w * s_w
-                const float inv = f16x2_inv_scale(absmax_read(x_slot)) * f16x2_inv_scale(split_w_absmax(w_slot));
+            if constexpr (F16) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
