@@ -131,6 +131,9 @@ PRECISION_EVIDENCE = {
     "ten_step_trajectory": "ten consecutive steps from one initial state, fp32 CPU oracle vs exact-f32 HIP vs f16x2 HIP: both HIP runs drift from the oracle at "
                            "the same rate (1e-7 at step 0, 1e-4 at step 2, ~1.3e-2 at steps 7-9; worst deviation f16x2 1.7e-2, exact-f32 1.3e-2) -- "
                            "profiles/r04_ten_step_trajectory.txt, tests/test_gpu_step.py::test_ten_step_trajectory_f16x2_tracks_the_oracle_like_exact_f32",
+    "three_hundred_steps": "300 steps at the headline workload from one seed: parameter-arena distance to an exact-f32 run (G / D) at step 300 -- a second "
+                           "exact-f32 run 5.9e-2 / 5.3e-2 (the step is not bit-reproducible and GAN training amplifies it), f16x2 6.0e-2 / 5.2e-2, bf16x3 "
+                           "6.2e-2 / 5.6e-2; no non-finite loss -- profiles/r04_long_run_300_steps.txt, tools/long_run.py",
     "reference_fixtures": "same bars as the exact-f32 step against the reference's fixtures (losses 1e-3, gradient norms 2e-3, 3 configs, all steps): "
                           "tests/test_gpu_step.py::test_train_step_f16x2_precision",
     "bare_mfma_probe": "32x32 tile, K = 576 .. 65536: f16x2 2.7e-7 .. 3.6e-6 vs the fp32 FMA chain / v_mfma_f32_32x32x2_f32 3.2e-7 .. 3.4e-6 -- "
