@@ -74,6 +74,9 @@ typedef float f32x2s __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
+#ifndef SP_EPI_FAST
+#define SP_EPI_FAST 1             // straight-line wide epilogue for tiles with every output in range (0: the predicated form for every tile)
+#endif
 #ifndef SP_ABLATE
 #define SP_ABLATE 0               // diagnostics (tools/variants.py): 1 no weight DMA, 2 no patch loads, 4 no split / patch stores, 8 no MFMA, 16 no output stores
 #endif
@@ -638,6 +641,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         }
         // ---- epilogue of this tile; the producers are already staging the next tile
         {
+            SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 3584, slab, 0);
             int cn, cty, ctx;
             tile_coords(tile, cn, cty, ctx);
             const int mrow0 = m0 + 4 * lh;
@@ -683,6 +687,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) acc[mi][ni][rr] = tanhf(acc[mi][ni][rr]);
             }
+            SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 3584, slab, 1);
             // one image's M x OH x OW outputs are < 2^30 (sp_launch): a uniform image pointer + 32-bit lane offsets, one
             // multiply-add per element (round 1: a 64-bit address and a bounds branch per element, ~5700 cycles per tile)
             const unsigned ohw = (unsigned)(g.OH * g.OW);
@@ -705,6 +710,39 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                 float* const S = reinterpret_cast<float*>(smem + S_base) + wn * 1024;
                 const int prow = lane >> 3, pq = lane & 7;
                 const int ox = ctx * 32 + 4 * pq;
+                // A tile with every output in range (wave-uniform test; all but the map's last row / column of tiles): straight-line code,
+                // so that a block's 4 read-backs -- and its 4 residual loads -- are in flight together.  The predicated form below
+                // compiles to one exec-masked region per store, each with its own LDS round trip and, with a residual, its own
+                // global-load wait (ISA of round 4: 16 serial `ds_read_b128; s_waitcnt lgkmcnt(0); global_store` per tile, 3500 of the
+                // epilogue's 4400 cycles in the s_memtime trace; this form 2300.  Measured and not kept: all four blocks' LDS round trips
+                // issued back to back and then the 16 stores -- 3200-4400 cycles, a `global_store_dwordx4` issues in ~200 when the four
+                // consumer waves store together, and the read-backs no longer hide under the previous block's stores).
+                const bool interior = SP_EPI_FAST && NCW == 4 && full_m && ctx * 32 + 32 <= GW && cty * TH + wn * NI + NI <= GH;
+                if (interior) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int ao = cty * TH + wn * NI + ni;
+                        const unsigned o0 = (unsigned)(m0 + prow) * ohw + (unsigned)((ao + g.py[ph]) * g.OW + ox + g.px[ph]);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            f32x4s r[4], v[4];
+                            if (res) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4s*>(rimg + (o0 + (unsigned)(mi * 32 + 8 * i) * ohw));
+                            }
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) S[((rr & 3) + 8 * (rr >> 2) + 4 * lh) * 32 + l31] = acc[mi][ni][rr];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4s*>(S + (prow + 8 * i) * 32 + 4 * pq);
+                            if (res) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] += r[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4s*>(yimg + (o0 + (unsigned)(mi * 32 + 8 * i) * ohw)) = v[i];
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int ao = cty * TH + wn * NI + ni;
@@ -746,12 +784,14 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                     }
                 }
             }
+            SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 3584, slab, 2);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            SPTRACE(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 3584, slab, 3);
         }
         if (!has_next) break;
         tile = next_tile;

@@ -24,3 +24,8 @@ for i in range(24):
     nxt = d(c[i + 1][0], c[i][3])
     print("%4d | %6d %6d %6d %6d | %6d %6d %6d %6d" % (16 + i, d(p[i][0], pl[i][0]), d(p[i][1], p[i][0]), d(p[i][2], p[i][1]), d(p[i][3], p[i][2]),
           d(c[i][1], c[i][0]), d(c[i][2], c[i][1]), d(c[i][3], c[i][2]), nxt))
+e = t[3584:3712].reshape(32, 4)
+print("epilogue of consumer wave 0 (stamped at the slab index that follows it): scale + bias + activation | transpose + stores issued | re-zero")
+for i in range(0, 32):
+    if e[i][0]:
+        print("%4d | %6d %6d %6d" % (16 + i, d(e[i][1], e[i][0]), d(e[i][2], e[i][1]), d(e[i][3], e[i][2])))
