@@ -717,7 +717,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                 // epilogue's 4400 cycles in the s_memtime trace; this form 2300.  Measured and not kept: all four blocks' LDS round trips
                 // issued back to back and then the 16 stores -- 3200-4400 cycles, a `global_store_dwordx4` issues in ~200 when the four
                 // consumer waves store together, and the read-backs no longer hide under the previous block's stores).
-                const bool interior = SP_EPI_FAST && NCW == 4 && full_m && ctx * 32 + 32 <= GW && cty * TH + wn * NI + NI <= GH;
+                const bool interior = SP_EPI_FAST && (SP_ABLATE & 16) == 0 && NCW == 4 && full_m && ctx * 32 + 32 <= GW && cty * TH + wn * NI + NI <= GH;
                 if (interior) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
@@ -769,6 +769,39 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
                 const int ao = cty * TH + wn * NI + ni;
                 if (ao < GH && bo < GW) {
                     const unsigned o0 = (unsigned)mrow0 * ohw + (unsigned)((ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]));
+                    if (SP_EPI_FAST && (SP_ABLATE & 16) == 0 && full_m) {
+                        // the (split-K, residual) case decided once, then straight-line code: the general form below compiles to one region per
+                        // register with those branches inside and an `s_waitcnt vmcnt(0)` in front of EVERY store (it waits for the load the
+                        // region may have issued -- and with it for every earlier store's acknowledgement: 64 serial round trips per tile.
+                        // Transposed 128 -> 64 4x4 stride 2 @128^2: 191 -> 141-146 us; the step 63.0-64.3 -> 60.8-61.2 ms)
+                        auto emit = [&](auto atomic_c, auto res_c) {
+                            constexpr bool AT = decltype(atomic_c)::value, RS = decltype(res_c)::value;
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                float r[16];
+                                if constexpr (RS) {
+#pragma unroll
+                                    for (int rr = 0; rr < 16; ++rr) r[rr] = rimg[o0 + (unsigned)(mi * 32 + (rr & 3) + 8 * (rr >> 2)) * ohw];
+                                }
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr) {
+                                    float* const p = yimg + (o0 + (unsigned)(mi * 32 + (rr & 3) + 8 * (rr >> 2)) * ohw);
+                                    float v = acc[mi][ni][rr];
+                                    if constexpr (RS) v += r[rr];
+                                    if constexpr (AT) atomicAdd(p, v);
+                                    else *p = v;
+                                }
+                            }
+                        };
+                        const bool use_res = res && ks == 0;
+                        if (ksplit > 1) {
+                            if (use_res) emit(std::true_type{}, std::true_type{});
+                            else emit(std::true_type{}, std::false_type{});
+                        } else {
+                            if (use_res) emit(std::false_type{}, std::true_type{});
+                            else emit(std::false_type{}, std::false_type{});
+                        }
+                    } else
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll

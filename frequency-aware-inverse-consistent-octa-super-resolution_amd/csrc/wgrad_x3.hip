@@ -294,14 +294,28 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(const float* __restrict__
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // two-pass (ws): this slice's partial dW, plain stores (wgrad_reduce_kernel); else atomics into dW.  The choice is made once and
+        // the read-backs go twelve at a time: with `if (ws)` inside the loop every element compiled to its own
+        // `ds_read_b32; s_waitcnt lgkmcnt(0); store` region, 144 serial LDS round trips per block
+        auto flush = [&](auto two_pass) {
+            float* const out = decltype(two_pass)::value ? ws + (long)slice * g.dw_elems : dw;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) {
-            const int e = lane + 64 * i;                                 // element of [8 rows][288 = 32 channels x 9 taps]
-            const int row = e / 288, col = e - row * 288;
-            const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + col;
-            if (ws) ws[(long)slice * g.dw_elems + o] = stage[e];         // two-pass: this slice's partial dW, plain stores (wgrad_reduce_kernel)
-            else atomicAdd(dw + o, stage[e]);
-        }
+            for (int i0 = 0; i0 < 36; i0 += 12) {
+                float v[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = stage[lane + 64 * (i0 + i)];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const int e = lane + 64 * (i0 + i);                  // element of [8 rows][288 = 32 channels x 9 taps]
+                    const int row = e / 288, col = e - row * 288;
+                    const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + col;
+                    if constexpr (decltype(two_pass)::value) out[o] = v[i];
+                    else atomicAdd(out + o, v[i]);
+                }
+            }
+        };
+        if (ws) flush(std::true_type{});
+        else flush(std::false_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -558,16 +572,29 @@ __global__ __launch_bounds__(512) void wgrad_x3_row_kernel(const float* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto flush = [&](auto two_pass) {                                // as in wgrad_x3_kernel: the (ws) choice once, read-backs in groups
+            float* const out = decltype(two_pass)::value ? ws + (long)slice * g.dw_elems : dw;
+            constexpr int NE = (8 * 32 * KW + 63) / 64;                  // 8 * 32 * KW is a multiple of 64 (4 KW elements per lane)
+            static_assert(8 * 32 * KW % 64 == 0, "whole waves of elements");
+            constexpr int NB = KW == 7 ? 7 : KW == 4 ? 8 : 6;             // read-backs in flight together
+            static_assert(NE % NB == 0, "whole batches");
 #pragma unroll
-        for (int i = 0; i < (8 * 32 * KW + 63) / 64; ++i) {
-            const int e = lane + 64 * i;                                 // element of [8 rows][32 channels][KW taps]
-            if (e < 8 * 32 * KW) {
-                const int row = e / (32 * KW), rem = e - row * (32 * KW), ch = rem / KW, t = rem - ch * KW;
-                const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + (long)ch * g.wsc + t;
-                if (ws) ws[(long)slice * g.dw_elems + o] = stage[e];
-                else atomicAdd(dw + o, stage[e]);
+            for (int i0 = 0; i0 < NE; i0 += NB) {
+                float v[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) v[i] = stage[lane + 64 * (i0 + i)];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int e = lane + 64 * (i0 + i);                  // element of [8 rows][32 channels][KW taps]
+                    const int row = e / (32 * KW), rem = e - row * (32 * KW), ch = rem / KW, t = rem - ch * KW;
+                    const long o = (long)(m0 + mh * 32 + 8 * j + row) * g.wsm + col_base + (long)ch * g.wsc + t;
+                    if constexpr (decltype(two_pass)::value) out[o] = v[i];
+                    else atomicAdd(out + o, v[i]);
+                }
             }
-        }
+        };
+        if (ws) flush(std::true_type{});
+        else flush(std::false_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
