@@ -395,6 +395,9 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         // 9 DMA + 8 loads of 1 KiB per wave took 2700 cycles with the MFMA waves parked at a barrier, 3400 beside them): issued in
         // a bunch a wave just sits in front of a full queue; with ~12 vector instructions between two of them the queue has
         // drained when the next one arrives.
+        // (Round 4, measured and not kept: the row cursor advanced by additions instead of `plane * w_plane + rr * w_row` per DMA -- the ISA
+        // goes from ~22 scalar instructions with three 64-bit multiplies per DMA to ~12 with none, and nothing changes: 64 -> 64 @256^2
+        // 122.4-132.7 vs 127.2-129.9 us, the step 60.3-61.8 vs 60.6 ms.  The producers' phase is not bound by its scalar work.)
         const char* d_src = wbase;                                       // row cursor of the slab being fetched
         char* d_dst = smem;
         int d_r = 0, d_rows = 0, d_rows2 = 0;
