@@ -189,6 +189,28 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
     const int ao = r0 / GW, bo = r0 - ao * GW;
     const long ohw = (long)g.OH * g.OW;
     const long obase = (long)no * g.M * ohw + (long)(ao * g.SO + g.py[ph]) * g.OW + (bo * g.SO + g.px[ph]);
+    // The bias / split-K cases are decided once and a block whose 128 rows all exist runs straight-line code: with the branches inside
+    // the per-register loop every element compiled to its own region -- `global_load_dword (bias); s_waitcnt vmcnt(0); store`, 32 serial
+    // memory round trips per thread (round 4's ISA)
+    const bool use_bias = bias && ks == 0;
+    if (m0 + NM_MT <= g.M) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int mb = m0 + wm * 64 + mi * 32 + 4 * lh;
+            float bv[16];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) bv[rr] = use_bias ? bias[mb + (rr & 3) + 8 * (rr >> 2)] : 0.f;
+            if (ksplit > 1) {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) atomicAdd(y + obase + (long)(mb + (rr & 3) + 8 * (rr >> 2)) * ohw, acc[mi][rr] + bv[rr]);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr)
+                    y[obase + (long)(mb + (rr & 3) + 8 * (rr >> 2)) * ohw] = act_apply(acc[mi][rr] + bv[rr], g.act, g.slope);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_nm_kernel(const float* __restrict__
             const int m = m0 + wm * 64 + mi * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
             if (m < g.M) {
                 float v = acc[mi][rr];
-                if (bias && ks == 0) v += bias[m];
+                if (use_bias) v += bias[m];
                 if (ksplit > 1) atomicAdd(y + obase + (long)m * ohw, v);
                 else y[obase + (long)m * ohw] = act_apply(v, g.act, g.slope);
             }

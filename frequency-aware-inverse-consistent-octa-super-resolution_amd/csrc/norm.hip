@@ -308,13 +308,21 @@ __global__ __launch_bounds__(256) void norm_fwd_small_kernel(const float* __rest
     bool ok[K];
     row_chunk_offsets<K>(R, HW, r, L, off, ok);
     const float shift = x[(long)r * HW];
+    // Every chunk is LOADED (a chunk beyond the row reads the row's first 16 bytes: row_chunk_offsets) and the out-of-row ones are
+    // replaced afterwards: with `ok[k] ? ld4(..) : ..` each load compiled to its own exec-masked region ending in `s_waitcnt vmcnt(0)`
+    // -- K serial memory round trips (round 4's ISA; 256 x 32^2 rows, batch 8: 7.5-7.7 -> 6.2-7.3 us per launch).  The streaming kernels' second chunk has the same
+    // predicated form; loading it unconditionally from a clamped address was measured too and is not kept: they already move 5-6 TB/s and
+    // the 64 x 256^2 backward pass got slower (128 -> 136 us)
     float4 v[K], rr[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = ok[k] ? ld4(x + off[k]) : make_float4(shift, shift, shift, shift);
+    for (int k = 0; k < K; ++k) v[k] = ld4(x + off[k]);
     if (res) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) rr[k] = ok[k] ? ld4(res + off[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) rr[k] = ld4(res + off[k]);
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (!ok[k]) v[k] = make_float4(shift, shift, shift, shift);
     float a = 0.f, q = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
