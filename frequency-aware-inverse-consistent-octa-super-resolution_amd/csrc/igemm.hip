@@ -315,6 +315,10 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const float* __restric
         }
         __syncthreads();
         if (ch + 1 < ch_end) load_chunk(ch + 1);
+        // (Round 4, measured and not kept: all 32 fragment reads of the chunk first, then its 16 MFMAs behind counted waits, here and in
+        // igemm_gather_kernel -- the compiled loop is `ds_read2_b32 x2; s_waitcnt lgkmcnt(0); v_mfma x2` eight times.  Slower: 256 -> 512
+        // 4x4 stride 2 @32^2 weight gradient 137 -> 155 us, 512 -> 512 @16^2 76-84 -> 88-89; these blocks are 4 waves with several blocks
+        // per CU, and the other waves already cover a wave's LDS round trip.)
 #pragma unroll
         for (int kk0 = 0; kk0 < PJ; kk0 += 2) {
             const float af = A_s[(wm * 32 + l31) * LD + kk0 + lh];
