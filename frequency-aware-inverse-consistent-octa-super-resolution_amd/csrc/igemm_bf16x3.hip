@@ -60,9 +60,14 @@ extern "C" int faoctasr_sp_trace_read(unsigned* host_out, int n) {
     if (!host_out || n < 0 || n > 4096) return -1;
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(faoctasr_sp_trace_buf), sizeof(unsigned) * (size_t)n) == hipSuccess ? 0 : -3;
 }
-#define SPTRACE(cond, base, q, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (cond) && (q) >= 16 && (q) < 48) faoctasr_sp_trace_buf[(base) + ((q) - 16) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#ifndef SP_TRACE_Q0
+#define SP_TRACE_Q0 16            // first slab recorded (32 slabs fit); 0 for layers whose blocks run a single tile
+#endif
+#define SPTRACE(cond, base, q, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (cond) && (q) >= SP_TRACE_Q0 && (q) < SP_TRACE_Q0 + 32) faoctasr_sp_trace_buf[(base) + ((q) - SP_TRACE_Q0) * 4 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define SPTRACE0(cond, slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (cond)) faoctasr_sp_trace_buf[(slot)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SPTRACE(cond, base, q, k) do { } while (0)
+#define SPTRACE0(cond, slot) do { } while (0)
 #endif
 
 namespace faoctasr {
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
     constexpr int MI = 2, TH = NCW * NI, NT = 256, NPI = SP_NPI;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SPTRACE0(tid == 0, 8);                                              // kernel entry
     const int l31 = lane & 31, lh = lane >> 5;
     const bool producer = (SP_PROD_FIRST && NCW == 4) ? wave < 4 : wave >= NCW;
     const int wn = NCW == 4 ? wave & 3 : (wave >= NCW ? wave - NCW : wave), stid = tid & 255;      // consumer index 0 .. NCW-1 / producer index 0 .. 3
@@ -472,7 +478,9 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
             load_patch(grp_l);                                           // patch 1
             advance_l();
         }
+        SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 9);    // first patch split + stored, second patch's loads issued
         barrier_keep(0);
+        SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 10);   // ... and the first weight slab landed
         long tile = blockIdx.x;
         int slab = 0, pcount = 0;
         while (true) {
@@ -832,6 +840,7 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         if (!has_next) break;
         tile = next_tile;
     }
+    SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 256 : 0), 11);          // consumer wave 0: last epilogue issued
 }
 
 // ---------------------------------------------------------------------------------------------------------------
