@@ -209,8 +209,8 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         constexpr unsigned OOB = 0x80000000u;
         const unsigned cstep = 4u * (unsigned)chw;
         const float* xin = x;
-        float sx = 1.f;                                                  // f16x2: the activation tensor's scale (wave-uniform)
-        if constexpr (F16) sx = f16x2_scale(absmax_read(x_slot));
+        float sx = 1.f;                                                  // f16x2: the activation tensor's scale (wave-uniform); read below, behind
+                                                                         // the first patch's loads: it is not needed before the first split
         // ---- single-pixel items (all of the patch when !QUAD)
         constexpr int NSI = QUAD ? 2 : NPI;
         unsigned poff[NSI];
@@ -466,12 +466,16 @@ __global__ __launch_bounds__(64 * (NCW + 4)) void igemm_bf16x3_kernel(const floa
         };
         auto no_hook = [&]() {};
 
+        SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 12);   // producer set-up done
         compute_poff(tile_l);
         load_patch(grp_l);                                               // patch 0
+        SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 13);   // first patch's loads issued
         advance_l();
         begin_A(g0, 0, 0);
         if constexpr (SP_CDMA != 0) d_rows2 = (SP_ABLATE & 1) ? 0 : 2 * d_rows;      // slab 0 is the producers' in every variant
         rest_of_A();
+        SPTRACE0(tid == ((SP_PROD_FIRST && NCW == 4) ? 0 : 64 * NCW), 14);   // first weight slab's DMAs issued
+        if constexpr (F16) sx = f16x2_scale(absmax_read(x_slot));
         store_patch(0, no_hook);
         int in_flight = 0;
         if (valid_l) {

@@ -27,6 +27,7 @@ for i in range(24):
           d(c[i][1], c[i][0]), d(c[i][2], c[i][1]), d(c[i][3], c[i][2]), nxt))
 Q0 = int(__import__("os").environ.get("SP_TRACE_Q0", "16"))             # the build's -DSP_TRACE_Q0 (labels only)
 print("block 0: kernel entry -> first patch stored %d, -> first barrier passed %d, -> consumer's last epilogue issued %d cycles" % (d(t[9], t[8]), d(t[10], t[8]), d(t[11], t[8])))
+print("   producer wave 4: set-up done %d, first patch's loads issued %d, first weight slab's DMAs issued %d cycles after kernel entry" % (d(t[12], t[8]), d(t[13], t[8]), d(t[14], t[8])))
 print("first recorded consumer slab starts %d cycles after kernel entry" % d(c[0][0], t[8]))
 e = t[3584:3712].reshape(32, 4)
 print("epilogue of consumer wave 0 (stamped at the slab index that follows it): scale + bias + activation | transpose + stores issued | re-zero")
