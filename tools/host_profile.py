@@ -10,7 +10,7 @@ import torch
 import faoctasr
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-ts = faoctasr.TrainStep(device="cuda")
+ts = faoctasr.TrainStep(device="cuda", precision=(sys.argv[2] if len(sys.argv) > 2 else "f16x2"))
 g = torch.Generator().manual_seed(0)
 a = (torch.rand(B, 1, 256, 256, generator=g) * 2 - 1).cuda()
 b = (torch.rand(B, 1, 256, 256, generator=g) * 2 - 1).cuda()
