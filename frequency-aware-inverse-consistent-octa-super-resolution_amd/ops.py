@@ -6,6 +6,7 @@ every arithmetic kernel is ours.  Weight / affine gradients are accumulated by t
 straight into ``param.grad`` when that already exists (the flat gradient arena of
 train.TrainStep), so no per-parameter add kernels run and the all-reduce sees one buffer.
 """
+import contextlib
 import ctypes
 import math
 
@@ -274,18 +275,32 @@ class PackPlan:
         self.njobs, self.nblocks = len(blobs), base
         self.table = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.float32).to(device) if blobs else None   # raw bytes, carried as fp32
 
-    def run(self):
-        """False (nothing launched) when a weight has moved or died since the jobs were recorded: the owner drops the plan."""
+    def run(self, aside=None):
+        """False (nothing launched) when a weight has moved or died since the jobs were recorded: the owner drops the plan.
+
+        ``aside``: a stream to pack on instead of the current one (ordered behind the current stream's work so far).  Readers on that
+        stream see the images in stream order; readers on any other stream are ordered behind the launch by the event ``_wpack``
+        already honours for images packed inside a convolution call."""
         live = [(e, e.wref()) for e, _ in self.entries]
         if any(w is None or w.data_ptr() != p for (e, w), (_, p) in zip(live, self.entries)):
             return False
+        event = ev_stream = None
         if self.njobs:
-            if self.precision == 3:                 # f16x2 images: the weights' absmax slots first
-                call("conv_pack_scales", ptr(self.table), self.njobs, stream_ptr())
-            call("conv_pack_run", ptr(self.table), self.njobs, self.nblocks, stream_ptr())
+            if aside is not None:
+                cur = torch.cuda.current_stream()
+                if cur.cuda_stream == aside.cuda_stream:
+                    aside = None
+                else:
+                    aside.wait_stream(cur)
+            with torch.cuda.stream(aside) if aside is not None else contextlib.nullcontext():
+                if self.precision == 3:             # f16x2 images: the weights' absmax slots first
+                    call("conv_pack_scales", ptr(self.table), self.njobs, stream_ptr())
+                call("conv_pack_run", ptr(self.table), self.njobs, self.nblocks, stream_ptr())
+                if aside is not None:
+                    event, ev_stream = aside.record_event(), aside.cuda_stream
         for e, w in live:
             e.ver = _ver(w)
-            e.event = e.ev_stream = None      # written here, on the stream every role of the step forks from
+            e.event, e.ev_stream = event, ev_stream      # None: written on the stream every role of the step forks from
         return True
 
 

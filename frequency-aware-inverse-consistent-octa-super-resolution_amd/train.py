@@ -9,6 +9,7 @@ per-sample frequency split (the reference supports batch 1 only: SURVEY.md fact 
 """
 import ctypes
 import math
+import os
 import random
 import struct
 
@@ -253,6 +254,9 @@ class TrainStep:
     #: "deferred": on the side stream, but the launches of one backward pass are collected and enqueued there in one batch when the
     #: pass is over -- one fork + join per backward pass in the graph (ops.end_wgrad)
     capture_side_wgrad = False
+    #: eager multi-stream steps: the discriminators' packed-weight images are written on a branch stream under the generators' forward
+    #: (False: behind the generators' images on the caller's stream, as in captured and single-stream steps)
+    pack_D_aside = os.environ.get("FAOCTASR_PACK_D_ASIDE", "1") != "0"
 
     def __init__(self, netG_A2B=None, netG_B2A=None, netD_A=None, netD_B=None, device="cuda", lr=1.3e-4, betas=(0.9, 0.999),
                  beta1=0.25, beta2=10.0, beta3=2.0, beta4=0.5, beta5=0.5, ssim_weight=0.0, whf_weight=0.0, dwt_levels=1,
@@ -648,8 +652,16 @@ class TrainStep:
         ops.reproducible_forward = self.reproducible_forward
         misses = ops.pack_misses
         plan_key = (tuple(real_A.shape), tuple(real_B.shape), self.precision)
-        plan = self._pack_plans.get(plan_key)
-        packed = plan is not None and plan.run()        # every packed-weight image of a step of this shape in one launch
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        streams = self.overlap_wgrad and self._side is not None and (capturing or real_A.numel() >= self.overlap_min_pixels)
+        plans = self._pack_plans.get(plan_key)
+        # every packed-weight image of a step of this shape in two launches: the generators' on the caller's stream, the discriminators'
+        # (two thirds of the bytes: their exact-f32 narrow-map images) on a branch stream in eager multi-stream steps -- nothing reads them
+        # before the generators' forward has run, and a reader on another stream waits for the launch's event (ops._wpack)
+        packed = False
+        if plans is not None:
+            aside = self._branch[0] if (streams and not capturing and self.pack_D_aside) else None
+            packed = plans[0].run() and plans[1].run(aside)
         if not packed:
             self._pack_plans.pop(plan_key, None)
         # a plan built after this step (a pack miss: new shape, or a weight that moved) then holds exactly the images THIS step used --
@@ -659,10 +671,8 @@ class TrainStep:
         # below ~2 x 256^2 pixels per batch the step is bound by the host's enqueue rate, and the extra events / stream switches
         # of the schedule cost more than the concurrency returns (batch 1 at 256^2: 41.8 vs 39.3 ms; batch 2: 48.3 vs 52.8)
         # ... a CAPTURED step has no host in its way: there the schedule pays at every size (batch 1: 29.9 against 35.4 ms per replay)
-        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if capturing:
             _guard.begin(torch.cuda.current_stream(self.device).cuda_stream)
-        streams = self.overlap_wgrad and self._side is not None and (capturing or real_A.numel() >= self.overlap_min_pixels)
         set_requires_grad([self.netD_A, self.netD_B], False)                # train.py:219 (before the first discriminator pass)
         self.opt_G.zero_grad()                                              # train.py:220 (before the first backward of a generator term)
         # (a step without a plan -- the first of its shape -- packs inside its convolution calls; ops._wpack orders a later reader on
@@ -745,7 +755,7 @@ class TrainStep:
             # some convolution packed its own weights: first step of this shape / precision -> collect the images this step used
             if len(self._pack_plans) >= 8:
                 self._pack_plans.pop(next(iter(self._pack_plans)))
-            self._pack_plans[plan_key] = ops.PackPlan(self.opt_G.params + self.opt_D.params, ops.conv_precision)
+            self._pack_plans[plan_key] = (ops.PackPlan(self.opt_G.params, ops.conv_precision), ops.PackPlan(self.opt_D.params, ops.conv_precision))
         ops.conv_precision = 0
         ops.reproducible_forward = False
         out = {k: v.detach() for k, v in L.items()}
