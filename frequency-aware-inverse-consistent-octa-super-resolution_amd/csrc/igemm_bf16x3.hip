@@ -1018,6 +1018,8 @@ static int sp_launch(const float* x, const float* wp, const float* bias, float* 
 // Eight consumer waves (two per SIMD) + four producers: a 16-row x 32-pixel tile per block (512 pixels per 64 output channels).  Taken
 // for stride-1 single-phase layers whose 512-pixel tiles still give every CU at least two tiles, when the 4-pixel patch items and the
 // 16-byte epilogue apply; the tap group shrinks to <= 5 taps so that the two weight buffers leave room for the larger patch.
+// (Round 4: tried again with the f16x2 operands and the straight-line epilogue -- 64 -> 64 @256^2 148.7 us against 128.7-134.9 for the 4 + 4 form,
+// 64 -> 128 @128^2 73 against 66.5, the step 61.2-61.4 against 59.6-59.8 ms on that box: still off.)
 static int sp_launch_wide_block(const float* x, const float* wp, const float* bias, float* y, SplitGeom g, hipStream_t s) {
     if (!SP_NCW8 || g.f16 || g_conv_residual_live || g.SI != 1 || g.nphase != 1) return 0;
     constexpr int TH = 16;
